@@ -1,0 +1,131 @@
+/*
+ * mic_oracle.h -- CPU restatement of the MIC parallel-strip hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  The shipped path is
+ * medical-image-codec_amd/csrc (HIP) behind include/mic_hip.h.
+ *
+ * Every function restates the Go reference (pappuks/medical-image-codec) and
+ * cites the file:line it follows.  Parity pinning: see oracle/README.md --
+ * the restatement is byte-compared against the reference's own C codec
+ * (ojph/mic_compress_c.c, built in place into oracle/_ref/) and against the
+ * committed golden vectors in tests/golden/.
+ */
+#ifndef MIC_ORACLE_H
+#define MIC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes (shared numbering with include/mic_hip.h). */
+#define MICO_OK                  0
+#define MICO_ERR_ARGS           -1
+#define MICO_ERR_NOMEM          -2
+#define MICO_ERR_USE_RLE        -3   /* Go ErrUseRLE        (fseu16.go:36) */
+#define MICO_ERR_CAPACITY       -5
+#define MICO_ERR_CORRUPT        -6
+#define MICO_ERR_INTERNAL       -8
+#define MICO_ERR_INCOMPRESSIBLE -10  /* Go ErrIncompressible (fseu16.go:33) */
+
+/* ---- L2: delta(avg)+RLE  (deltarlecompressu16.go, rlecompressu16.go) ---- */
+/* out capacity: 4*w*h + 16 u16 is always enough. */
+int mico_delta_rle_compress(const uint16_t *px, int w, int h, uint16_t max_value,
+                            uint16_t *out, size_t cap, size_t *out_n);
+int mico_delta_rle_decompress(const uint16_t *in, size_t n, int w, int h,
+                              uint16_t *px);
+/* Intermediate stage: delta symbols before RLE (for kernel-stage parity). */
+int mico_delta_symbols(const uint16_t *px, int w, int h, uint16_t max_value,
+                       uint16_t *out, size_t cap, size_t *out_n);
+/* RleCompressU16.Init(len,1,max).Compress(input)  (rlecompressu16.go:85-93) */
+int mico_rle_compress(const uint16_t *in, size_t n, uint16_t max_value,
+                      uint16_t *out, size_t cap, size_t *out_n);
+/* RleDecompressU16.Init(in).Decompress()          (rledecompressu16.go:87-97) */
+int mico_rle_decompress(const uint16_t *in, size_t n, uint16_t *out, size_t cap,
+                        size_t *out_n);
+
+/* ---- L1: FSE / tANS with a 16-bit alphabet ------------------------------ */
+/* nstates: 1 (fsecompressu16.go:19), 2 (fse2state.go:22), 4 (fse4state.go:24),
+ * 8 (fse8state.go:31), 108 = rANS-8 (rans8state.go:31). */
+int mico_fse_compress(const uint16_t *in, size_t n, int nstates,
+                      uint8_t *out, size_t cap, size_t *out_len);
+/* FSEDecompressU16Auto (fse2state.go:102-116). */
+int mico_fse_decompress_auto(const uint8_t *in, size_t len,
+                             uint16_t *out, size_t cap, size_t *out_n);
+
+/* Table-level probes used by stage-parity tests of the HIP kernels. */
+typedef struct {
+    uint32_t symbol_len;
+    uint32_t max_count;
+    uint8_t  table_log;
+    uint8_t  zero_bits;
+} mico_fse_info;
+/* histogram+tableLog+normalise; norm must hold 65536 entries */
+int mico_fse_normalize(const uint16_t *in, size_t n, int32_t *norm,
+                       mico_fse_info *info);
+
+/* ---- L3: unit codec (multiframecompress.go:15-107) ---------------------- */
+/* nstates 2 -> CompressSingleFrame, 4 -> ...4State, 8 -> ...8State
+ * (fallback chains N -> ... -> 1 as in the reference). */
+int mico_compress_single_frame(const uint16_t *px, int w, int h,
+                               uint16_t max_value, int nstates,
+                               uint8_t *out, size_t cap, size_t *out_len);
+int mico_decompress_single_frame(const uint8_t *in, size_t len,
+                                 uint16_t *px, int w, int h);
+
+/* ---- L4: PICS strips (parallelstrips.go:55-330) ------------------------- */
+int mico_pics_compress(const uint16_t *px, int w, int h, uint16_t max_value,
+                       int num_strips, int nstates,
+                       uint8_t *out, size_t cap, size_t *out_len);
+/* returns dims through w/h; px may be NULL to only parse the header */
+int mico_pics_decompress(const uint8_t *in, size_t len, uint16_t *px,
+                         size_t px_cap, int *w, int *h);
+
+/* ---- L4: MIC2 independent + temporal (multiframe*.go) ------------------- */
+int mico_mic2_compress(const uint16_t *frames, int w, int h, int nframes,
+                       uint16_t max_value, int temporal,
+                       uint8_t *out, size_t cap, size_t *out_len);
+int mico_mic2_decompress(const uint8_t *in, size_t len, uint16_t *frames,
+                         size_t px_cap, int *w, int *h, int *nframes);
+
+/* ---- wavelet V2 (waveletu16.go, waveletfsecompressu16.go:303-534) ------- */
+int mico_wavelet_v2_compress(const uint16_t *px, int rows, int cols,
+                             uint16_t max_value, int levels,
+                             uint8_t *out, size_t cap, size_t *out_len);
+int mico_wavelet_v2_decompress(const uint8_t *in, size_t len, uint16_t *px,
+                               size_t px_cap, int *rows, int *cols);
+/* forward transform only (coefficient-level parity): data is rows x cols i32 */
+int mico_wt53_forward(int32_t *data, int rows, int cols, int levels,
+                      int *applied);
+int mico_wt53_inverse(int32_t *data, int rows, int cols, int levels);
+
+/* ---- MIC3 / WSI (wsicompress.go, wsiformat.go, ycocgr.go) --------------- */
+void mico_ycocgr_forward(const uint8_t *rgb, int npx, uint16_t *y, uint16_t *co,
+                         uint16_t *cg);
+void mico_ycocgr_inverse(const uint16_t *y, const uint16_t *co,
+                         const uint16_t *cg, int npx, uint8_t *rgb);
+/* compressRGBTileBlob (wsicompress.go:319-364) on one tw x th RGB tile */
+int mico_wsi_compress_tile(const uint8_t *rgb, int tw, int th,
+                           uint8_t *out, size_t cap, size_t *out_len);
+int mico_wsi_decompress_tile(const uint8_t *in, size_t len, int tw, int th,
+                             uint8_t *rgb);
+/* CompressWSI with default options (256x256 tiles, colour transform, auto
+ * pyramid levels) for 8-bit RGB. */
+int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h,
+                      int levels /* 0 = auto */,
+                      uint8_t *out, size_t cap, size_t *out_len);
+int mico_wsi_decompress_tile_at(const uint8_t *in, size_t len, int level,
+                                int tx, int ty, uint8_t *rgb, size_t cap,
+                                int *tw, int *th);
+
+/* FNV-1a 64 of a byte buffer (fixture hashing helper) */
+uint64_t mico_fnv1a64(const uint8_t *p, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
