@@ -1,0 +1,178 @@
+/*
+ * mic_hip.h -- C ABI of libmic_hip.so, the MI355X (gfx950) implementation of MIC's
+ * parallel-strip encode/decode hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The
+ * reference's Go package reaches it through cgo exactly as it reaches its own C codec
+ * today (reference: ojph/mic_c.go:11-19); INTEGRATION.md shows the binding.
+ *
+ * Conventions (reference: ojph/mic_compress_c.h:26-38, ojph/mic_decompress_c.h:24-50,
+ * ojph/mic_parallel.h:49-57):
+ *   - the caller allocates every buffer; the library keeps no caller pointer after return;
+ *   - 0 = success, negative = error class (MIC_ERR_*);
+ *   - every entry point is thread-safe and may be called concurrently from any OS thread
+ *     (reference: mic_parallel.h:47-48);
+ *   - encoders take the caller's max_value: the Go API passes it
+ *     (multiframecompress.go:15), the reference C derives it (mic_compress_c.c:774-775).
+ *
+ * There is no CPU fallback: every call fails with MIC_ERR_DEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef MIC_HIP_H
+#define MIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------------- */
+#define MIC_OK                   0
+#define MIC_ERR_ARGS            -1   /* bad pointer / dimension (mic_compress_c.c:918) */
+#define MIC_ERR_NOMEM           -2
+#define MIC_ERR_USE_RLE         -3   /* Go ErrUseRLE, fseu16.go:36; C: mic_compress_c.c:852 */
+#define MIC_ERR_CAPACITY        -5   /* output buffer too small (mic_compress_c.c:865) */
+#define MIC_ERR_CORRUPT         -6   /* malformed stream (mic_decompress_c.c:1004-1063) */
+#define MIC_ERR_DEVICE          -7   /* HIP runtime / no gfx950 device */
+#define MIC_ERR_INTERNAL        -8
+#define MIC_ERR_UNSUPPORTED     -9
+#define MIC_ERR_INCOMPRESSIBLE -10   /* Go ErrIncompressible, fseu16.go:33; C: -4 / -10 */
+
+/* FSE flavour requested from an encoder: the entry of the reference's fallback chain
+ * (multiframecompress.go:15-93).  2 -> CompressSingleFrame (2-state, then 1-state),
+ * 4 -> CompressSingleFrame4State (4 -> 2 -> 1), 8 -> CompressSingleFrame8State. */
+#define MIC_STATES_2 2
+#define MIC_STATES_4 4
+#define MIC_STATES_8 8
+
+/* ---- library / device ------------------------------------------------------------- */
+/* Selects the HIP device used by subsequent calls of the calling process (default 0).
+ * Returns MIC_ERR_DEVICE when the device does not exist or is not gfx950. */
+int mic_hip_set_device(int device);
+/* "gfx950 <n CUs> ..." style description of the active device; "" if none. */
+const char *mic_hip_device_name(void);
+const char *mic_hip_version(void);
+
+/* ---- unit codec: one frame / strip / plane ----------------------------------------- */
+/* Replaces CompressSingleFrame{,4State,8State} (multiframecompress.go:15,38,67) and
+ * mic_compress_{two,four,eight}_state (ojph/mic_compress_c.h:26-38).
+ * out_cap >= 2*width*height + 4096 is always sufficient. */
+int mic_hip_compress_frame(const uint16_t *pixels, int width, int height,
+                           uint16_t max_value, int nstates,
+                           uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* Replaces DecompressSingleFrame (multiframecompress.go:97) and
+ * mic_decompress_{two,four,eight}_state (ojph/mic_decompress_c.h:24-50): the FSE flavour
+ * (1/2/4/8-state, rANS-8) is auto-detected as in FSEDecompressU16Auto (fse2state.go:102). */
+int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len,
+                             uint16_t *pixels_out, int width, int height);
+
+/* ---- batch: many independent units in one call (one cgo crossing, one launch chain) --- */
+/* Replaces the goroutine fan-out of parallelstrips.go:77-93 / :292-321, the frame loop of
+ * multiframecompress.go:186-209 and the tile worker pool of wsicompress.go:126-145. */
+typedef struct mic_hip_enc_job {
+    const uint16_t *pixels;   /* in : width*height u16, row-major (host memory) */
+    int32_t   width, height;  /* in  */
+    uint16_t  max_value;      /* in  */
+    uint16_t  nstates;        /* in : MIC_STATES_2/4/8 */
+    uint8_t  *out;            /* in : caller buffer */
+    size_t    out_cap;        /* in  */
+    size_t    out_len;        /* out */
+    int32_t   status;         /* out: MIC_OK or MIC_ERR_* for this unit */
+    int32_t   nstates_used;   /* out: 8/4/2/1 flavour actually written */
+} mic_hip_enc_job;
+
+typedef struct mic_hip_dec_job {
+    const uint8_t *compressed; /* in  (host memory) */
+    size_t    compressed_len;  /* in  */
+    uint16_t *pixels_out;      /* in : width*height u16 (host memory) */
+    int32_t   width, height;   /* in  */
+    int32_t   status;          /* out */
+} mic_hip_dec_job;
+
+/* Return value: MIC_OK when the batch ran (inspect per-job status), or a global error. */
+int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs);
+int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs);
+
+/* ---- PICS container --------------------------------------------------------------------- */
+/* Replaces CompressParallelStrips{,4State,8State} (parallelstrips.go:55,128,199).
+ * num_strips <= 0 is rejected with MIC_ERR_ARGS: the Go default (GOMAXPROCS) is a host
+ * property and stays on the Go side.  out_cap >= 2*w*h + 4096 + 8*num_strips + 20. */
+int mic_hip_pics_compress(const uint16_t *pixels, int width, int height,
+                          uint16_t max_value, int num_strips, int nstates,
+                          uint8_t *out, size_t out_cap, size_t *out_len);
+/* Header probe (parallelstrips.go:271-286). */
+int mic_hip_pics_info(const uint8_t *compressed, size_t compressed_len,
+                      int *width, int *height, int *num_strips, int *strip_height);
+/* Replaces DecompressParallelStrips (parallelstrips.go:270) and mic_decompress_parallel
+ * (ojph/mic_parallel.h:49-52; max_threads has no meaning on the GPU and is dropped).
+ * width/height must equal the header's. */
+int mic_hip_pics_decompress(const uint8_t *compressed, size_t compressed_len,
+                            uint16_t *pixels_out, int width, int height);
+
+/* ---- MIC2 container, independent frames --------------------------------------------------- */
+/* Replaces CompressMultiFrame(..., temporal=false) (multiframecompress.go:179) +
+ * WriteMIC2 (multiframe.go:49).  frames = nframes*width*height u16, frame-major. */
+int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nframes,
+                          uint16_t max_value,
+                          uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_mic2_info(const uint8_t *compressed, size_t compressed_len,
+                      int *width, int *height, int *nframes, int *temporal);
+/* Replaces DecompressMultiFrame (multiframecompress.go:227) for independent-mode files. */
+int mic_hip_mic2_decompress(const uint8_t *compressed, size_t compressed_len,
+                            uint16_t *frames_out, size_t frames_cap_px);
+
+/* ---- device-resident sessions (inputs and outputs stay in HBM) ------------------------------ */
+/* A session owns the workspace for up to max_units units of up to max_px pixels each and
+ * runs the same kernels as the calls above on data that is already on the device.  This is
+ * what bench.py times; it is also what a caller that produces / consumes pixels on the GPU
+ * should use.  All pointers named d_* are device pointers. */
+typedef struct mic_hip_session mic_hip_session;
+
+int  mic_hip_session_create(mic_hip_session **s, int max_units, size_t max_px_per_unit);
+void mic_hip_session_destroy(mic_hip_session *s);
+
+typedef struct mic_hip_unit {
+    uint64_t px_offset;     /* first pixel of the unit, in u16 elements from d_pixels */
+    int32_t  width, height;
+    uint16_t max_value;
+    uint16_t nstates;
+} mic_hip_unit;
+
+/* Encode n units.  Compressed blobs are left in the session; *d_blobs receives the device
+ * address of a packed buffer holding them back to back, h_offsets[n+1] (host) their byte
+ * offsets, h_status[n] the per-unit status, h_nstates[n] (may be NULL) the flavour written.
+ * Synchronous with respect to the host. */
+int mic_hip_session_encode(mic_hip_session *s, const uint16_t *d_pixels,
+                           const mic_hip_unit *units, int n,
+                           const uint8_t **d_blobs, uint64_t *h_offsets,
+                           int32_t *h_status, int32_t *h_nstates);
+/* Decode n units whose compressed blobs are in d_blobs at h_offsets[i]..h_offsets[i+1];
+ * pixels are written to d_pixels_out at units[i].px_offset. */
+int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs,
+                           const uint64_t *h_offsets, const mic_hip_unit *units, int n,
+                           uint16_t *d_pixels_out, int32_t *h_status);
+/* Asynchronous forms used for timing: enqueue all kernels of a pass on the session's
+ * stream (returned by mic_hip_session_stream as a hipStream_t) without touching the host;
+ * results are fetched with the *_finish calls. */
+void *mic_hip_session_stream(mic_hip_session *s);
+int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels,
+                                   const mic_hip_unit *units, int n);
+int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs,
+                                  uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates);
+int mic_hip_session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs,
+                                   const uint64_t *h_offsets, const mic_hip_unit *units, int n,
+                                   uint16_t *d_pixels_out);
+int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status);
+/* Enables (1) / disables (0) per-kernel HIP-event timing of the enqueue calls. */
+int mic_hip_session_set_timing(mic_hip_session *s, int enabled);
+/* Per-kernel device time (ms, HIP events on the session stream) of the last enqueue:
+ * names[i] / ms[i], returns the number of entries written (<= cap). */
+int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIC_HIP_H */

@@ -1,0 +1,346 @@
+"""medical-image-codec_amd: MI355X (gfx950) implementation of MIC's parallel-strip hot path.
+
+This package is a thin ctypes binding over the C ABI of ``libmic_hip.so``
+(``include/mic_hip.h``) -- the same entry points the reference's Go package binds through
+cgo.  Function names mirror the reference's Go API
+(``parallelstrips.go``, ``multiframecompress.go``) so tests read like the reference's.
+
+There is no CPU fallback: importing works without a GPU (for symbol checks), but every
+codec call raises ``MicError`` unless the HIP library runs on a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmic_hip.so")
+
+MIC_OK = 0
+MIC_ERR_ARGS = -1
+MIC_ERR_NOMEM = -2
+MIC_ERR_USE_RLE = -3
+MIC_ERR_CAPACITY = -5
+MIC_ERR_CORRUPT = -6
+MIC_ERR_DEVICE = -7
+MIC_ERR_INTERNAL = -8
+MIC_ERR_UNSUPPORTED = -9
+MIC_ERR_INCOMPRESSIBLE = -10
+
+_ERR_NAMES = {
+    MIC_ERR_ARGS: "bad arguments", MIC_ERR_NOMEM: "out of memory",
+    MIC_ERR_USE_RLE: "input is single value repeated",        # ErrUseRLE, fseu16.go:36
+    MIC_ERR_CAPACITY: "output buffer too small", MIC_ERR_CORRUPT: "corrupt stream",
+    MIC_ERR_DEVICE: "no usable gfx950 device / HIP error", MIC_ERR_INTERNAL: "internal error",
+    MIC_ERR_UNSUPPORTED: "unsupported", MIC_ERR_INCOMPRESSIBLE: "input is not compressible",  # fseu16.go:33
+}
+
+
+class MicError(RuntimeError):
+    def __init__(self, code: int, where: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {_ERR_NAMES.get(code, 'error')} (rc={code})")
+
+
+class ErrUseRLE(MicError):
+    """Reference sentinel ErrUseRLE (fseu16.go:36)."""
+
+
+class ErrIncompressible(MicError):
+    """Reference sentinel ErrIncompressible (fseu16.go:33)."""
+
+
+def _raise(code: int, where: str):
+    if code == MIC_ERR_USE_RLE:
+        raise ErrUseRLE(code, where)
+    if code == MIC_ERR_INCOMPRESSIBLE:
+        raise ErrIncompressible(code, where)
+    raise MicError(code, where)
+
+
+class EncJob(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_value", C.c_uint16), ("nstates", C.c_uint16),
+                ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_len", C.c_size_t),
+                ("status", C.c_int32), ("nstates_used", C.c_int32)]
+
+
+class DecJob(C.Structure):
+    _fields_ = [("compressed", C.c_void_p), ("compressed_len", C.c_size_t),
+                ("pixels_out", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("status", C.c_int32)]
+
+
+class Unit(C.Structure):
+    _fields_ = [("px_offset", C.c_uint64), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_value", C.c_uint16), ("nstates", C.c_uint16)]
+
+
+# every symbol include/mic_hip.h declares (tests/test_abi.py checks the .so exports them all)
+ABI_SYMBOLS = [
+    "mic_hip_set_device", "mic_hip_device_name", "mic_hip_version",
+    "mic_hip_compress_frame", "mic_hip_decompress_frame",
+    "mic_hip_compress_batch", "mic_hip_decompress_batch",
+    "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
+    "mic_hip_mic2_compress", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
+    "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
+    "mic_hip_session_encode", "mic_hip_session_decode",
+    "mic_hip_session_encode_enqueue", "mic_hip_session_encode_finish",
+    "mic_hip_session_decode_enqueue", "mic_hip_session_decode_finish",
+    "mic_hip_session_set_timing", "mic_hip_session_last_timings",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Loads libmic_hip.so (built in-tree by csrc/build.sh); fails loudly when missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run medical-image-codec_amd/csrc/build.sh "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.mic_hip_device_name.restype = C.c_char_p
+    L.mic_hip_version.restype = C.c_char_p
+    L.mic_hip_session_stream.restype = C.c_void_p
+    L.mic_hip_session_stream.argtypes = [C.c_void_p]
+    L.mic_hip_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
+    L.mic_hip_session_destroy.argtypes = [C.c_void_p]
+    L.mic_hip_session_destroy.restype = None
+    L.mic_hip_compress_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int,
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_decompress_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    L.mic_hip_compress_batch.argtypes = [C.POINTER(EncJob), C.c_int]
+    L.mic_hip_decompress_batch.argtypes = [C.POINTER(DecJob), C.c_int]
+    L.mic_hip_pics_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_pics_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
+    L.mic_hip_pics_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    L.mic_hip_mic2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint16,
+                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_mic2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
+    L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.mic_hip_session_encode_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Unit), C.c_int]
+    L.mic_hip_session_encode_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.mic_hip_session_decode_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                                 C.POINTER(Unit), C.c_int, C.c_void_p]
+    L.mic_hip_session_decode_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.mic_hip_session_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.mic_hip_session_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    _lib = L
+    return L
+
+
+def device_name() -> str:
+    return lib().mic_hip_device_name().decode()
+
+
+def _u16(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    return a
+
+
+def _bytes_arr(b) -> np.ndarray:
+    return np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ unit codec
+def compress_single_frame(pixels, width: int, height: int, max_value: int, nstates: int = 2) -> bytes:
+    """CompressSingleFrame / 4State / 8State (multiframecompress.go:15,38,67)."""
+    px = _u16(pixels).reshape(-1)
+    if px.size != width * height:
+        raise MicError(MIC_ERR_ARGS, "compress_single_frame")
+    cap = px.size * 2 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_compress_frame(px.ctypes.data, width, height, max_value, nstates, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_single_frame")
+    return out[: n.value].tobytes()
+
+
+def decompress_single_frame(compressed, width: int, height: int) -> np.ndarray:
+    """DecompressSingleFrame (multiframecompress.go:97)."""
+    c = _bytes_arr(compressed)
+    out = np.empty(width * height, dtype=np.uint16)
+    rc = lib().mic_hip_decompress_frame(c.ctypes.data, c.size, out.ctypes.data, width, height)
+    if rc:
+        _raise(rc, "decompress_single_frame")
+    return out.reshape(height, width)
+
+
+def compress_batch(frames: Sequence[np.ndarray], max_values: Sequence[int], nstates: int = 2
+                   ) -> List[Tuple[int, bytes, int]]:
+    """One launch chain over many frames; returns [(status, blob, nstates_used)]."""
+    n = len(frames)
+    arrs = [_u16(f) for f in frames]
+    outs = [np.empty(a.size * 2 + 4096, dtype=np.uint8) for a in arrs]
+    jobs = (EncJob * n)()
+    for i, a in enumerate(arrs):
+        h, w = a.shape
+        jobs[i].pixels = a.ctypes.data; jobs[i].width = w; jobs[i].height = h
+        jobs[i].max_value = int(max_values[i]); jobs[i].nstates = nstates
+        jobs[i].out = outs[i].ctypes.data; jobs[i].out_cap = outs[i].size
+    rc = lib().mic_hip_compress_batch(jobs, n)
+    if rc:
+        _raise(rc, "compress_batch")
+    return [(jobs[i].status, outs[i][: jobs[i].out_len].tobytes() if jobs[i].status == 0 else b"", jobs[i].nstates_used)
+            for i in range(n)]
+
+
+def decompress_batch(blobs: Sequence[bytes], dims: Sequence[Tuple[int, int]]) -> List[Tuple[int, Optional[np.ndarray]]]:
+    n = len(blobs)
+    cs = [_bytes_arr(b) for b in blobs]
+    outs = [np.empty(w * h, dtype=np.uint16) for (w, h) in dims]
+    jobs = (DecJob * n)()
+    for i in range(n):
+        jobs[i].compressed = cs[i].ctypes.data; jobs[i].compressed_len = cs[i].size
+        jobs[i].pixels_out = outs[i].ctypes.data; jobs[i].width = dims[i][0]; jobs[i].height = dims[i][1]
+    rc = lib().mic_hip_decompress_batch(jobs, n)
+    if rc:
+        _raise(rc, "decompress_batch")
+    return [(jobs[i].status, outs[i].reshape(dims[i][1], dims[i][0]) if jobs[i].status == 0 else None) for i in range(n)]
+
+
+# ------------------------------------------------------------------ PICS
+def compress_parallel_strips(pixels, width: int, height: int, max_value: int, num_strips: int, nstates: int = 2) -> bytes:
+    """CompressParallelStrips / 4State / 8State (parallelstrips.go:55,128,199)."""
+    px = _u16(pixels).reshape(-1)
+    if px.size != width * height:
+        raise MicError(MIC_ERR_ARGS, "parallelstrips: pixel count != width*height")
+    cap = px.size * 2 + 4096 * (max(num_strips, 1) + 1) + 8 * max(num_strips, 1) + 20
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_pics_compress(px.ctypes.data, width, height, max_value, num_strips, nstates, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_parallel_strips")
+    return out[: n.value].tobytes()
+
+
+def pics_info(compressed) -> Tuple[int, int, int, int]:
+    c = _bytes_arr(compressed)
+    w, h, n, sh = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_pics_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(n), C.byref(sh))
+    if rc:
+        _raise(rc, "parallelstrips")
+    return w.value, h.value, n.value, sh.value
+
+
+def decompress_parallel_strips(compressed) -> Tuple[np.ndarray, int, int]:
+    """DecompressParallelStrips (parallelstrips.go:270): returns (pixels, width, height)."""
+    c = _bytes_arr(compressed)
+    w, h, _, _ = pics_info(c)
+    out = np.empty(w * h, dtype=np.uint16)
+    rc = lib().mic_hip_pics_decompress(c.ctypes.data, c.size, out.ctypes.data, w, h)
+    if rc:
+        _raise(rc, "decompress_parallel_strips")
+    return out.reshape(h, w), w, h
+
+
+# ------------------------------------------------------------------ MIC2
+def compress_multi_frame(frames: np.ndarray, width: int, height: int, max_value: int, temporal: bool = False) -> bytes:
+    """CompressMultiFrame (multiframecompress.go:179), independent mode."""
+    if temporal:
+        raise MicError(MIC_ERR_UNSUPPORTED, "compress_multi_frame(temporal=True)")
+    fr = _u16(frames)
+    nframes = fr.shape[0]
+    cap = fr.size * 2 + 4096 * (nframes + 1) + 8 * nframes + 20
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_mic2_compress(fr.ctypes.data, width, height, nframes, max_value, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_multi_frame")
+    return out[: n.value].tobytes()
+
+
+def decompress_multi_frame(compressed) -> np.ndarray:
+    """DecompressMultiFrame (multiframecompress.go:227)."""
+    c = _bytes_arr(compressed)
+    w, h, n, t = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_mic2_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(n), C.byref(t))
+    if rc:
+        _raise(rc, "decompress_multi_frame")
+    out = np.empty(max(n.value, 0) * max(w.value, 0) * max(h.value, 0), dtype=np.uint16)
+    rc = lib().mic_hip_mic2_decompress(c.ctypes.data, c.size, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "decompress_multi_frame")
+    return out.reshape(n.value, h.value, w.value)
+
+
+# ------------------------------------------------------------------ device-resident sessions
+class Session:
+    """mic_hip_session: encode/decode units that already live in HBM.  Device pointers are
+    plain integers (e.g. ``torch.Tensor.data_ptr()``); torch itself is not needed here."""
+
+    def __init__(self, max_units: int, max_px_per_unit: int):
+        self._h = C.c_void_p()
+        rc = lib().mic_hip_session_create(C.byref(self._h), max_units, max_px_per_unit)
+        if rc:
+            _raise(rc, "session_create")
+        self._n = 0
+
+    def close(self):
+        if self._h:
+            lib().mic_hip_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return lib().mic_hip_session_stream(self._h) or 0
+
+    def set_timing(self, on: bool):
+        lib().mic_hip_session_set_timing(self._h, 1 if on else 0)
+
+    def last_timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        k = lib().mic_hip_session_last_timings(self._h, names, ms, 32)
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    @staticmethod
+    def make_units(units: Sequence[Tuple[int, int, int, int, int]]):
+        arr = (Unit * len(units))()
+        for i, (off, w, h, mv, ns) in enumerate(units):
+            arr[i].px_offset = off; arr[i].width = w; arr[i].height = h; arr[i].max_value = mv; arr[i].nstates = ns
+        return arr
+
+    def encode_enqueue(self, d_pixels: int, units):
+        rc = lib().mic_hip_session_encode_enqueue(self._h, d_pixels, units, len(units))
+        if rc:
+            _raise(rc, "session_encode_enqueue")
+        self._n = len(units)
+
+    def encode_finish(self):
+        n = self._n
+        offs = (C.c_uint64 * (n + 1))(); st = (C.c_int32 * n)(); ns = (C.c_int32 * n)()
+        d = C.c_void_p()
+        rc = lib().mic_hip_session_encode_finish(self._h, C.byref(d), offs, st, ns)
+        if rc:
+            _raise(rc, "session_encode_finish")
+        return d.value, np.array(offs[:], dtype=np.uint64), np.array(st[:], dtype=np.int32), np.array(ns[:], dtype=np.int32)
+
+    def decode_enqueue(self, d_blobs: int, offsets: np.ndarray, units, d_pixels_out: int):
+        offs = (C.c_uint64 * len(offsets))(*[int(v) for v in offsets])
+        rc = lib().mic_hip_session_decode_enqueue(self._h, d_blobs, offs, units, len(units), d_pixels_out)
+        if rc:
+            _raise(rc, "session_decode_enqueue")
+        self._n = len(units)
+
+    def decode_finish(self) -> np.ndarray:
+        st = (C.c_int32 * self._n)()
+        rc = lib().mic_hip_session_decode_finish(self._h, st)
+        if rc:
+            _raise(rc, "session_decode_finish")
+        return np.array(st[:], dtype=np.int32)

@@ -1,0 +1,641 @@
+// mic_api.hip -- host side of libmic_hip.so: the C ABI of include/mic_hip.h, the HIP batch
+// launcher that replaces the reference's goroutine / pthread fan-out
+// (parallelstrips.go:77-93, mic_parallel.c:146-181, wsicompress.go:126-145) and the
+// PICS / MIC2 container assembly (parallelstrips.go:101-123, multiframe.go:49-91).
+//
+// There is no CPU codec in this file: every pixel and every compressed byte is produced by
+// the kernels in mic_encode.hip / mic_decode.hip.  The host only moves buffers, fills unit
+// descriptors and writes container headers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mic_hip.h"
+#include "mic_dev.h"
+
+#include "mic_launch.h"
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            if (getenv("MIC_HIP_DEBUG"))                                                  \
+                fprintf(stderr, "mic_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? MIC_ERR_NOMEM : MIC_ERR_DEVICE;            \
+        }                                                                                 \
+    } while (0)
+
+namespace {
+
+std::mutex g_mu;            // serialises the default session (entry points are re-entrant)
+int g_device = 0;
+bool g_device_ok = false;
+std::string g_device_name;
+
+int ensure_device() {
+    if (g_device_ok) { return hipSetDevice(g_device) == hipSuccess ? MIC_OK : MIC_ERR_DEVICE; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || g_device >= n) return MIC_ERR_DEVICE;
+    HIP_TRY(hipSetDevice(g_device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, g_device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return MIC_ERR_DEVICE;   // code objects are gfx950 only
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s %d CUs %.0f GiB (%s)", p.gcnArchName, p.multiProcessorCount,
+             (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), p.name);
+    g_device_name = buf;
+    g_device_ok = true;
+    return MIC_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return MIC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return MIC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr size_t kSym = 65536;
+
+inline size_t tok_cap_for(size_t px) { return 4 * px + 16; }
+inline size_t blob_cap_for(size_t px) { return 8 + 131080 + 2 * tok_cap_for(px) + 16; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct mic_hip_session {
+    int max_units = 0; size_t max_px = 0;
+    hipStream_t stream = nullptr;
+    DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets;
+    DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
+    std::vector<MicUnit> h_units;
+    std::vector<uint64_t> h_off;
+    int n_last = 0;
+    int variant = 0;                        // kernel generation selector (0 = default)
+    MicTimer timer;
+    std::vector<std::string> t_names; std::vector<float> t_ms;
+    size_t tok_stride = 0, blob_stride = 0;
+
+    int ensure(int n, size_t px) {
+        if (!stream) HIP_TRY(hipStreamCreate(&stream));
+        if (n <= max_units && px <= max_px) return MIC_OK;
+        int nn = std::max(n, max_units); size_t pp = std::max(px, max_px);
+        tok_stride = align_up(tok_cap_for(pp) * 2, 256);
+        blob_stride = align_up(blob_cap_for(pp), 256);
+        int rc;
+        if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
+        if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
+        if ((rc = hist.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = norm.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_nb.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_find.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = state_tab.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tab_sym.reserve(kSym * 2 * (size_t)nn))) return rc;
+        if ((rc = cumul.reserve((kSym + 64) * 4 * (size_t)nn))) return rc;
+        if ((rc = blob.reserve(blob_stride * (size_t)nn))) return rc;
+        if ((rc = offsets.reserve(8 * ((size_t)nn + 1)))) return rc;
+        max_units = nn; max_px = pp;
+        return MIC_OK;
+    }
+    void fill_workspace(MicUnit &u, int i) {
+        u.tok = (uint16_t *)((char *)tok.p + tok_stride * (size_t)i);
+        u.tok_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
+        u.hist = (uint32_t *)hist.p + kSym * (size_t)i;
+        u.norm = (int32_t *)norm.p + kSym * (size_t)i;
+        u.tt_nb = (uint32_t *)tt_nb.p + kSym * (size_t)i;
+        u.tt_find = (int32_t *)tt_find.p + kSym * (size_t)i;
+        u.state_tab = (uint32_t *)state_tab.p + kSym * (size_t)i;
+        u.tab_sym = (uint16_t *)tab_sym.p + kSym * (size_t)i;
+        u.cumul = (int32_t *)cumul.p + (kSym + 64) * (size_t)i;
+        u.blob = (uint8_t *)blob.p + blob_stride * (size_t)i;
+        u.blob_cap = (uint32_t)std::min<size_t>(blob_cap_for(max_px), 0xFFFFFFF0u);
+    }
+    void release() {
+        DevBuf *all[] = { &units, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &io_px, &io_comp };
+        for (DevBuf *b : all) b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        timer.destroy();
+    }
+};
+
+namespace {
+
+mic_hip_session g_default;   // guarded by g_mu
+
+// ---- encode -------------------------------------------------------------------------------
+int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
+    if (n <= 0) return MIC_ERR_ARGS;
+    size_t max_px = 0;
+    for (int i = 0; i < n; i++) {
+        if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
+        max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
+    }
+    if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+    int rc = s->ensure(n, max_px);
+    if (rc) return rc;
+    s->h_units.assign((size_t)n, MicUnit{});
+    for (int i = 0; i < n; i++) {
+        MicUnit &u = s->h_units[(size_t)i];
+        u.px_in = d_pixels + units[i].px_offset;
+        u.w = units[i].width; u.h = units[i].height;
+        u.max_value = units[i].max_value; u.nstates = units[i].nstates;
+        s->fill_workspace(u, i);
+        u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
+        if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8)) return MIC_ERR_ARGS;
+    }
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)n, s->stream));
+    s->timer.reset(s->stream);
+    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant, &s->timer);
+    HIP_TRY(hipGetLastError());
+    s->n_last = n;
+    return MIC_OK;
+}
+
+int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
+    int n = s->n_last;
+    if (n <= 0) return MIC_ERR_ARGS;
+    HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        const MicUnit &u = s->h_units[(size_t)i];
+        h_offsets[i] = total;
+        if (u.status == MICD_OK) total += u.blob_len;
+        h_status[i] = u.status;
+        if (h_nstates) h_nstates[i] = u.nstates_used;
+    }
+    h_offsets[n] = total;
+    int rc = s->packed.reserve((size_t)total + 16);
+    if (rc) return rc;
+    mic_launch_pack((const MicUnit *)s->units.p, n, (uint64_t *)s->offsets.p, (uint8_t *)s->packed.p, s->stream, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (d_blobs) *d_blobs = (const uint8_t *)s->packed.p;
+    return MIC_OK;
+}
+
+// ---- decode -------------------------------------------------------------------------------
+int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
+                           const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
+    if (n <= 0) return MIC_ERR_ARGS;
+    size_t max_px = 0;
+    for (int i = 0; i < n; i++) {
+        if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
+        max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
+    }
+    if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+    int rc = s->ensure(n, max_px);
+    if (rc) return rc;
+    s->h_units.assign((size_t)n, MicUnit{});
+    for (int i = 0; i < n; i++) {
+        MicUnit &u = s->h_units[(size_t)i];
+        uint64_t len = h_offsets[i + 1] - h_offsets[i];
+        if (h_offsets[i + 1] < h_offsets[i] || len > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
+        u.comp_in = d_blobs + h_offsets[i]; u.comp_len = (uint32_t)len;
+        u.px_out = d_pixels_out + units[i].px_offset;
+        u.w = units[i].width; u.h = units[i].height;
+        s->fill_workspace(u, i);
+        u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
+    }
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    s->timer.reset(s->stream);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, &s->timer);
+    HIP_TRY(hipGetLastError());
+    s->n_last = n;
+    return MIC_OK;
+}
+
+int session_decode_finish(mic_hip_session *s, int32_t *h_status) {
+    int n = s->n_last;
+    if (n <= 0) return MIC_ERR_ARGS;
+    HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n; i++) h_status[i] = s->h_units[(size_t)i].status;
+    return MIC_OK;
+}
+
+// ---- host-pointer batches on the default session ---------------------------------------------
+// Units are processed in sub-batches that keep the workspace under a fixed budget.
+constexpr size_t kWorkspaceBudget = (size_t)24 << 30;
+
+size_t unit_ws_bytes(size_t px) { return tok_cap_for(px) * 2 + blob_cap_for(px) + kSym * 4 * 6 + kSym * 2 + 4096; }
+
+int compress_batch_locked(mic_hip_enc_job *jobs, int njobs) {
+    mic_hip_session *s = &g_default;
+    int i0 = 0;
+    while (i0 < njobs) {
+        size_t max_px = 0, tot_px = 0; int i1 = i0;
+        while (i1 < njobs) {
+            mic_hip_enc_job &j = jobs[i1];
+            if (!j.pixels || !j.out || j.width <= 0 || j.height <= 0 || (size_t)j.width * (size_t)j.height > ((size_t)1 << 28) ||
+                !(j.nstates == 2 || j.nstates == 4 || j.nstates == 8)) {
+                if (i1 == i0) { j.status = MIC_ERR_ARGS; j.out_len = 0; j.nstates_used = 0; i0++; i1++; continue; }
+                break;
+            }
+            size_t px = (size_t)j.width * (size_t)j.height;
+            size_t mp = std::max(max_px, px);
+            if (i1 > i0 && unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > kWorkspaceBudget) break;
+            max_px = mp; tot_px += px; i1++;
+        }
+        int n = i1 - i0;
+        if (n <= 0) continue;
+        int rc = s->io_px.reserve(tot_px * 2);
+        if (rc) return rc;
+        std::vector<mic_hip_unit> units((size_t)n);
+        size_t off = 0;
+        for (int k = 0; k < n; k++) {
+            mic_hip_enc_job &j = jobs[i0 + k];
+            size_t px = (size_t)j.width * (size_t)j.height;
+            HIP_TRY(hipMemcpyAsync((uint16_t *)s->io_px.p + off, j.pixels, px * 2, hipMemcpyHostToDevice, s->stream ? s->stream : 0));
+            units[(size_t)k] = mic_hip_unit{ off, j.width, j.height, j.max_value, j.nstates };
+            off += px;
+        }
+        if (!s->stream) HIP_TRY(hipDeviceSynchronize());
+        rc = session_encode_enqueue(s, (const uint16_t *)s->io_px.p, units.data(), n);
+        if (rc) return rc;
+        std::vector<uint64_t> offs((size_t)n + 1); std::vector<int32_t> st((size_t)n), ns((size_t)n);
+        const uint8_t *d_blobs = nullptr;
+        rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data());
+        if (rc) return rc;
+        std::vector<uint8_t> host((size_t)offs[(size_t)n] + 16);
+        if (offs[(size_t)n]) HIP_TRY(hipMemcpy(host.data(), d_blobs, (size_t)offs[(size_t)n], hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; k++) {
+            mic_hip_enc_job &j = jobs[i0 + k];
+            j.status = st[(size_t)k]; j.nstates_used = ns[(size_t)k]; j.out_len = 0;
+            if (j.status != MIC_OK) continue;
+            size_t len = (size_t)(offs[(size_t)k + 1] - offs[(size_t)k]);
+            if (len > j.out_cap) { j.status = MIC_ERR_CAPACITY; continue; }
+            memcpy(j.out, host.data() + offs[(size_t)k], len);
+            j.out_len = len;
+        }
+        i0 = i1;
+    }
+    return MIC_OK;
+}
+
+int decompress_batch_locked(mic_hip_dec_job *jobs, int njobs) {
+    mic_hip_session *s = &g_default;
+    int i0 = 0;
+    while (i0 < njobs) {
+        size_t max_px = 0, tot_px = 0, tot_comp = 0; int i1 = i0;
+        while (i1 < njobs) {
+            mic_hip_dec_job &j = jobs[i1];
+            if (!j.compressed || !j.pixels_out || j.width <= 0 || j.height <= 0 || j.compressed_len == 0 ||
+                j.compressed_len > 0xFFFFFFF0ull || (size_t)j.width * (size_t)j.height > ((size_t)1 << 28)) {
+                if (i1 == i0) { j.status = (j.compressed && j.compressed_len == 0) ? MIC_ERR_CORRUPT : MIC_ERR_ARGS; i0++; i1++; continue; }
+                break;
+            }
+            size_t px = (size_t)j.width * (size_t)j.height;
+            size_t mp = std::max(max_px, px);
+            if (i1 > i0 && unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > kWorkspaceBudget) break;
+            max_px = mp; tot_px += px; tot_comp += align_up(j.compressed_len, 16); i1++;
+        }
+        int n = i1 - i0;
+        if (n <= 0) continue;
+        int rc = s->io_px.reserve(tot_px * 2);
+        if (rc) return rc;
+        if ((rc = s->io_comp.reserve(tot_comp + 64))) return rc;
+        if ((rc = s->ensure(n, max_px))) return rc;
+        std::vector<mic_hip_unit> units((size_t)n);
+        std::vector<uint64_t> offs((size_t)n + 1);
+        // blobs are placed 16-byte aligned; decode takes explicit [begin,end) per unit
+        std::vector<uint64_t> begins((size_t)n), ends((size_t)n);
+        size_t poff = 0, coff = 0;
+        for (int k = 0; k < n; k++) {
+            mic_hip_dec_job &j = jobs[i0 + k];
+            HIP_TRY(hipMemcpyAsync((uint8_t *)s->io_comp.p + coff, j.compressed, j.compressed_len, hipMemcpyHostToDevice, s->stream));
+            begins[(size_t)k] = coff; ends[(size_t)k] = coff + j.compressed_len;
+            coff += align_up(j.compressed_len, 16);
+            units[(size_t)k] = mic_hip_unit{ poff, j.width, j.height, 0, 0 };
+            poff += (size_t)j.width * (size_t)j.height;
+        }
+        // session_decode_enqueue wants contiguous offsets; fill the descriptors directly instead
+        s->h_units.assign((size_t)n, MicUnit{});
+        for (int k = 0; k < n; k++) {
+            MicUnit &u = s->h_units[(size_t)k];
+            u.comp_in = (const uint8_t *)s->io_comp.p + begins[(size_t)k];
+            u.comp_len = (uint32_t)(ends[(size_t)k] - begins[(size_t)k]);
+            u.px_out = (uint16_t *)s->io_px.p + units[(size_t)k].px_offset;
+            u.w = units[(size_t)k].width; u.h = units[(size_t)k].height;
+            s->fill_workspace(u, k);
+            u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
+        }
+        HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+        mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr);
+        HIP_TRY(hipGetLastError());
+        s->n_last = n;
+        std::vector<int32_t> st((size_t)n);
+        rc = session_decode_finish(s, st.data());
+        if (rc) return rc;
+        for (int k = 0; k < n; k++) {
+            mic_hip_dec_job &j = jobs[i0 + k];
+            j.status = st[(size_t)k];
+            if (j.status != MIC_OK) continue;
+            HIP_TRY(hipMemcpyAsync(j.pixels_out, (uint16_t *)s->io_px.p + units[(size_t)k].px_offset,
+                                   (size_t)j.width * (size_t)j.height * 2, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        i0 = i1;
+    }
+    return MIC_OK;
+}
+
+void put_u32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+}  // namespace
+
+// ================================================================================ C ABI
+
+extern "C" {
+
+const char *mic_hip_version(void) { return "mic-hip 0.1 (gfx950)"; }
+
+int mic_hip_set_device(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (device < 0) return MIC_ERR_ARGS;
+    if (g_device_ok && device != g_device) { g_default.release(); g_default = mic_hip_session(); g_device_ok = false; }
+    g_device = device;
+    return ensure_device();
+}
+
+const char *mic_hip_device_name(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ensure_device() != MIC_OK) return "";
+    return g_device_name.c_str();
+}
+
+int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
+    if (!jobs || njobs < 0) return MIC_ERR_ARGS;
+    if (njobs == 0) return MIC_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!g_default.stream) HIP_TRY(hipStreamCreate(&g_default.stream));
+    return compress_batch_locked(jobs, njobs);
+}
+
+int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
+    if (!jobs || njobs < 0) return MIC_ERR_ARGS;
+    if (njobs == 0) return MIC_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!g_default.stream) HIP_TRY(hipStreamCreate(&g_default.stream));
+    return decompress_batch_locked(jobs, njobs);
+}
+
+int mic_hip_compress_frame(const uint16_t *pixels, int width, int height, uint16_t max_value, int nstates,
+                           uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!pixels || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
+    mic_hip_enc_job j{};
+    j.pixels = pixels; j.width = width; j.height = height; j.max_value = max_value; j.nstates = (uint16_t)nstates;
+    j.out = out; j.out_cap = out_cap;
+    if (!(nstates == 2 || nstates == 4 || nstates == 8)) return MIC_ERR_ARGS;
+    int rc = mic_hip_compress_batch(&j, 1);
+    if (rc) return rc;
+    if (j.status == MIC_OK) *out_len = j.out_len;
+    return j.status;
+}
+
+int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len, uint16_t *pixels_out, int width, int height) {
+    if (!compressed || !pixels_out || width <= 0 || height <= 0) return MIC_ERR_ARGS;
+    mic_hip_dec_job j{};
+    j.compressed = compressed; j.compressed_len = compressed_len; j.pixels_out = pixels_out; j.width = width; j.height = height;
+    int rc = mic_hip_decompress_batch(&j, 1);
+    if (rc) return rc;
+    return j.status;
+}
+
+// ---- PICS (parallelstrips.go) ----------------------------------------------------------------
+int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
+                          uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
+    if (!(nstates == 2 || nstates == 4 || nstates == 8)) return MIC_ERR_ARGS;
+    if (num_strips > height) num_strips = height;                    // parallelstrips.go:62-67
+    int strip_h = (height + num_strips - 1) / num_strips;            // :70
+    int actual = (height + strip_h - 1) / strip_h;                   // :72
+    size_t header = 20 + (size_t)actual * 8;
+    if (out_cap < header) return MIC_ERR_CAPACITY;
+    std::vector<mic_hip_enc_job> jobs((size_t)actual);
+    std::vector<std::vector<uint8_t>> bufs((size_t)actual);
+    for (int s = 0; s < actual; s++) {
+        int y0 = s * strip_h, y1 = std::min(height, y0 + strip_h);
+        mic_hip_enc_job &j = jobs[(size_t)s];
+        j = mic_hip_enc_job{};
+        j.pixels = pixels + (size_t)y0 * (size_t)width; j.width = width; j.height = y1 - y0;
+        j.max_value = max_value; j.nstates = (uint16_t)nstates;       // global maxValue for every strip, :88
+        bufs[(size_t)s].resize((size_t)width * (size_t)(y1 - y0) * 2 + 4096);
+        j.out = bufs[(size_t)s].data(); j.out_cap = bufs[(size_t)s].size();
+    }
+    int rc = mic_hip_compress_batch(jobs.data(), actual);
+    if (rc) return rc;
+    size_t total = 0;
+    for (int s = 0; s < actual; s++) {
+        if (jobs[(size_t)s].status != MIC_OK) return jobs[(size_t)s].status;   // first failing strip, :95-99
+        total += jobs[(size_t)s].out_len;
+    }
+    if (total > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;
+    if (out_cap < header + total) return MIC_ERR_CAPACITY;
+    memcpy(out, "PICS", 4);
+    put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height);
+    put_u32(out + 12, (uint32_t)actual); put_u32(out + 16, (uint32_t)strip_h);
+    size_t off = 0;
+    for (int s = 0; s < actual; s++) {
+        put_u32(out + 20 + (size_t)s * 8, (uint32_t)off);
+        put_u32(out + 24 + (size_t)s * 8, (uint32_t)jobs[(size_t)s].out_len);
+        memcpy(out + header + off, jobs[(size_t)s].out, jobs[(size_t)s].out_len);
+        off += jobs[(size_t)s].out_len;
+    }
+    *out_len = header + total;
+    return MIC_OK;
+}
+
+int mic_hip_pics_info(const uint8_t *c, size_t len, int *width, int *height, int *num_strips, int *strip_height) {
+    if (!c) return MIC_ERR_ARGS;
+    if (len < 20 || memcmp(c, "PICS", 4) != 0) return MIC_ERR_CORRUPT;   // parallelstrips.go:271-273
+    int w = (int)get_u32(c + 4), h = (int)get_u32(c + 8), n = (int)get_u32(c + 12), sh = (int)get_u32(c + 16);
+    if (n < 0 || (size_t)n > (len - 20) / 8) return MIC_ERR_CORRUPT;     // truncated header, :281-283
+    if (w <= 0 || h <= 0 || n <= 0 || sh <= 0) return MIC_ERR_CORRUPT;   // :284-286
+    if (width) *width = w; if (height) *height = h; if (num_strips) *num_strips = n; if (strip_height) *strip_height = sh;
+    return MIC_OK;
+}
+
+int mic_hip_pics_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) {
+    if (!c || !pixels_out) return MIC_ERR_ARGS;
+    int w, h, n, sh;
+    int rc = mic_hip_pics_info(c, len, &w, &h, &n, &sh);
+    if (rc) return rc;
+    if (w != width || h != height) return MIC_ERR_ARGS;
+    size_t header = 20 + (size_t)n * 8;
+    std::vector<mic_hip_dec_job> jobs((size_t)n);
+    for (int s = 0; s < n; s++) {
+        size_t so = get_u32(c + 20 + (size_t)s * 8), sl = get_u32(c + 24 + (size_t)s * 8);
+        size_t start = header + so, end = start + sl;
+        if (end > len || start > end) return MIC_ERR_CORRUPT;            // :300-304
+        long y0 = (long)s * sh, y1 = std::min<long>(h, y0 + sh);
+        if (y0 >= h) return MIC_ERR_CORRUPT;
+        mic_hip_dec_job &j = jobs[(size_t)s];
+        j = mic_hip_dec_job{};
+        j.compressed = c + start; j.compressed_len = sl;
+        j.pixels_out = pixels_out + (size_t)y0 * (size_t)w; j.width = w; j.height = (int)(y1 - y0);
+    }
+    rc = mic_hip_decompress_batch(jobs.data(), n);
+    if (rc) return rc;
+    for (int s = 0; s < n; s++) if (jobs[(size_t)s].status != MIC_OK) return jobs[(size_t)s].status;
+    return MIC_OK;
+}
+
+// ---- MIC2 independent mode (multiframe.go, multiframecompress.go:179-261) -----------------------
+int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
+                          uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!frames || !out || !out_len || width <= 0 || height <= 0 || nframes <= 0) return MIC_ERR_ARGS;
+    size_t npx = (size_t)width * (size_t)height;
+    size_t header = 20 + (size_t)nframes * 8;
+    if (out_cap < header) return MIC_ERR_CAPACITY;
+    std::vector<mic_hip_enc_job> jobs((size_t)nframes);
+    std::vector<uint8_t> buf((npx * 2 + 4096) * (size_t)nframes);
+    for (int i = 0; i < nframes; i++) {
+        mic_hip_enc_job &j = jobs[(size_t)i];
+        j = mic_hip_enc_job{};
+        j.pixels = frames + npx * (size_t)i; j.width = width; j.height = height; j.max_value = max_value; j.nstates = 2;
+        j.out = buf.data() + (npx * 2 + 4096) * (size_t)i; j.out_cap = npx * 2 + 4096;
+    }
+    int rc = mic_hip_compress_batch(jobs.data(), nframes);
+    if (rc) return rc;
+    size_t total = 0;
+    for (int i = 0; i < nframes; i++) { if (jobs[(size_t)i].status != MIC_OK) return jobs[(size_t)i].status; total += jobs[(size_t)i].out_len; }
+    if (total > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;              // u32 offsets, multiframe.go:75-80
+    if (out_cap < header + total) return MIC_ERR_CAPACITY;
+    memset(out, 0, header);
+    memcpy(out, "MIC2", 4);
+    put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height); put_u32(out + 12, (uint32_t)nframes);
+    out[16] = 0x01;                                                     // PipelineSpatial, multiframe.go:28
+    size_t off = 0;
+    for (int i = 0; i < nframes; i++) {
+        put_u32(out + 20 + (size_t)i * 8, (uint32_t)off);
+        put_u32(out + 24 + (size_t)i * 8, (uint32_t)jobs[(size_t)i].out_len);
+        memcpy(out + header + off, jobs[(size_t)i].out, jobs[(size_t)i].out_len);
+        off += jobs[(size_t)i].out_len;
+    }
+    *out_len = header + total;
+    return MIC_OK;
+}
+
+int mic_hip_mic2_info(const uint8_t *c, size_t len, int *width, int *height, int *nframes, int *temporal) {
+    if (!c) return MIC_ERR_ARGS;
+    if (len < 20 || memcmp(c, "MIC2", 4) != 0) return MIC_ERR_CORRUPT;   // multiframe.go:96-103
+    int w = (int)get_u32(c + 4), h = (int)get_u32(c + 8), n = (int)get_u32(c + 12);
+    if (n < 0 || (size_t)n > (len - 20) / 8) return MIC_ERR_CORRUPT;     // :112-116
+    if (width) *width = w; if (height) *height = h; if (nframes) *nframes = n; if (temporal) *temporal = (c[16] & 0x02) != 0;
+    return MIC_OK;
+}
+
+int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, size_t frames_cap_px) {
+    if (!c || !frames_out) return MIC_ERR_ARGS;
+    int w, h, n, temporal;
+    int rc = mic_hip_mic2_info(c, len, &w, &h, &n, &temporal);
+    if (rc) return rc;
+    if (temporal) return MIC_ERR_UNSUPPORTED;                            // temporal chain: SURVEY §8(f) "next"
+    if (w <= 0 || h <= 0 || n <= 0) return MIC_ERR_CORRUPT;
+    size_t npx = (size_t)w * (size_t)h;
+    if (npx * (size_t)n > frames_cap_px) return MIC_ERR_CAPACITY;
+    size_t data_off = 20 + (size_t)n * 8;
+    std::vector<mic_hip_dec_job> jobs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        size_t start = data_off + get_u32(c + 20 + (size_t)i * 8), bl = get_u32(c + 24 + (size_t)i * 8);
+        if (start + bl > len) return MIC_ERR_CORRUPT;                     // multiframe.go:137-139
+        mic_hip_dec_job &j = jobs[(size_t)i];
+        j = mic_hip_dec_job{};
+        j.compressed = c + start; j.compressed_len = bl; j.pixels_out = frames_out + npx * (size_t)i; j.width = w; j.height = h;
+    }
+    rc = mic_hip_decompress_batch(jobs.data(), n);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) if (jobs[(size_t)i].status != MIC_OK) return jobs[(size_t)i].status;
+    return MIC_OK;
+}
+
+// ---- sessions ------------------------------------------------------------------------------------
+int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_per_unit) {
+    if (!out || max_units <= 0 || max_px_per_unit == 0) return MIC_ERR_ARGS;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int rc = ensure_device();
+        if (rc) return rc;
+    }
+    mic_hip_session *s = new mic_hip_session();
+    int rc = s->ensure(max_units, max_px_per_unit);
+    if (rc) { s->release(); delete s; return rc; }
+    const char *v = getenv("MIC_HIP_VARIANT");
+    if (v) s->variant = atoi(v);
+    *out = s;
+    return MIC_OK;
+}
+void mic_hip_session_destroy(mic_hip_session *s) { if (s) { s->release(); delete s; } }
+void *mic_hip_session_stream(mic_hip_session *s) { return s ? (void *)s->stream : nullptr; }
+
+int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
+    if (!s || !d_pixels || !units) return MIC_ERR_ARGS;
+    return session_encode_enqueue(s, d_pixels, units, n);
+}
+int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
+    if (!s || !h_offsets || !h_status) return MIC_ERR_ARGS;
+    return session_encode_finish(s, d_blobs, h_offsets, h_status, h_nstates);
+}
+int mic_hip_session_encode(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n,
+                           const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
+    int rc = mic_hip_session_encode_enqueue(s, d_pixels, units, n);
+    if (rc) return rc;
+    return mic_hip_session_encode_finish(s, d_blobs, h_offsets, h_status, h_nstates);
+}
+int mic_hip_session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
+                                   const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
+    if (!s || !d_blobs || !h_offsets || !units || !d_pixels_out) return MIC_ERR_ARGS;
+    return session_decode_enqueue(s, d_blobs, h_offsets, units, n, d_pixels_out);
+}
+int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status) {
+    if (!s || !h_status) return MIC_ERR_ARGS;
+    return session_decode_finish(s, h_status);
+}
+int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets, const mic_hip_unit *units, int n,
+                           uint16_t *d_pixels_out, int32_t *h_status) {
+    int rc = mic_hip_session_decode_enqueue(s, d_blobs, h_offsets, units, n, d_pixels_out);
+    if (rc) return rc;
+    return mic_hip_session_decode_finish(s, h_status);
+}
+int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {
+    if (!s) return MIC_ERR_ARGS;
+    s->timer.enabled = enabled != 0;
+    return MIC_OK;
+}
+int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *ms, int cap) {
+    if (!s) return 0;
+    s->t_names.clear(); s->t_ms.clear();
+    if (s->timer.used >= 2) {
+        if (hipEventSynchronize(s->timer.pool[s->timer.used - 1]) != hipSuccess) return 0;
+        for (size_t i = 0; i + 1 < s->timer.used; i++) {
+            float v = 0.f;
+            if (hipEventElapsedTime(&v, s->timer.pool[i], s->timer.pool[i + 1]) != hipSuccess) v = -1.f;
+            s->t_names.push_back(s->timer.names[i]); s->t_ms.push_back(v);
+        }
+    }
+    int n = (int)std::min<size_t>(s->t_names.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; i++) { names[i] = s->t_names[(size_t)i].c_str(); ms[i] = s->t_ms[(size_t)i]; }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// mic_dev.h -- device-side data layout shared by the encode / decode kernels and the launcher.
+//
+// One "unit" is one independently coded stream of the reference: a PICS strip
+// (parallelstrips.go:77-93), a MIC2 frame (multiframecompress.go:186-209) or a MIC3 plane
+// (wsicompress.go:373-421).  The launcher fills an array of MicUnit in HBM; every kernel
+// is launched over that array (blockIdx.x or blockIdx.y = unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MIC_MAXSYM        65535u
+#define MIC_MIN_TABLELOG  5      // fseu16.go:26
+#define MIC_MAX_TABLELOG  16     // fseu16.go:23
+#define MIC_DEF_TABLELOG  11     // fseu16.go:25
+
+// status codes: keep in sync with include/mic_hip.h
+#define MICD_OK                  0
+#define MICD_ERR_ARGS           -1
+#define MICD_ERR_USE_RLE        -3
+#define MICD_ERR_CAPACITY       -5
+#define MICD_ERR_CORRUPT        -6
+#define MICD_ERR_INTERNAL       -8
+#define MICD_ERR_UNSUPPORTED    -9
+#define MICD_ERR_INCOMPRESSIBLE -10
+
+struct MicUnit {
+    // ---- inputs ------------------------------------------------------------------
+    const uint16_t *px_in;    // encode: source pixels (w*h u16)
+    uint16_t       *px_out;   // decode: destination pixels
+    const uint8_t  *comp_in;  // decode: compressed blob
+    uint32_t        comp_len;
+    int32_t         w, h;
+    uint16_t        max_value;
+    uint16_t        nstates;  // encode: requested flavour 2/4/8
+    // ---- per-unit workspace (HBM) ------------------------------------------------
+    uint16_t *tok;            // RLE token stream (encode: produced, decode: FSE output)
+    uint32_t  tok_cap;
+    uint32_t *hist;           // [65536] symbol histogram (fseu16.go:64)
+    int32_t  *norm;           // [65536] normalised counts (fseu16.go:65)
+    uint32_t *tt_nb;          // [65536] enc: symbolTT.deltaNbBits ; dec: dtab (newState | nbBits<<16)
+    int32_t  *tt_find;        // [65536] enc: symbolTT.deltaFindState ; dec: symbolNext scratch
+    uint32_t *state_tab;      // [65536] enc: stateTable
+    uint16_t *tab_sym;        // [65536] enc: tableSymbol ; dec: symbol of each state
+    int32_t  *cumul;          // [65538]
+    uint8_t  *blob;           // encode: staging output (NCount + bitstream, 6-byte prefix first)
+    uint32_t  blob_cap;
+    // ---- results -----------------------------------------------------------------
+    uint32_t ntok;            // number of u16 in tok
+    uint32_t blob_len;
+    int32_t  status;
+    int32_t  nstates_used;
+    uint32_t symbol_len;
+    uint32_t max_count;
+    uint32_t table_log;
+    uint32_t zero_bits;
+    uint32_t hdr_len;         // NCount header bytes
+    uint32_t bits_off;        // decode: offset of the bitstream inside comp_in
+    uint32_t count;           // decode: symbol count from the 6-byte prefix
+    uint32_t flavour;         // decode: 1/2/4/8, 108 = rANS-8
+};
+
+__device__ __forceinline__ int mic_len16(uint32_t v) { return v ? 32 - __clz(v) : 0; }
+// fseu16.go:170-172 -- Len32(v)-1, wraps to 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t mic_high_bits(uint32_t v) { return (uint32_t)(31 - __clz(v)) ; }
+__device__ __forceinline__ uint32_t mic_table_step(uint32_t size) { return (size >> 1) + (size >> 3) + 3; }

@@ -1,0 +1,29 @@
+// mic_launch.h -- launcher interface between mic_api.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "mic_dev.h"
+
+// Optional per-kernel timing: when enabled the launchers drop a HIP event on the launch
+// stream in front of every kernel (and one at the end); mic_hip_session_last_timings turns
+// consecutive events into per-kernel device milliseconds.
+struct MicTimer {
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> pool;
+    std::vector<const char *> names;   // names[i] labels the span ev[i] .. ev[i+1]
+    size_t used = 0;
+    void reset(hipStream_t s) { stream = s; used = 0; names.clear(); }
+    void mark(const char *name) {
+        if (!enabled) return;
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }
+        (void)hipEventRecord(pool[used++], stream);
+        names.push_back(name);
+    }
+    void destroy() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); used = 0; names.clear(); }
+};
+
+// variant: 0 = default (fastest validated kernels), 100 = v0 single-lane reference kernels.
+void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
+void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);

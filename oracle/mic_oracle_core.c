@@ -174,7 +174,8 @@ typedef void (*sym_sink)(void *ctx, uint16_t sym);
 static int delta_walk(const uint16_t *in, int width, int height,
                       uint16_t max_value, sym_sink sink, void *ctx) {
     int depth = len16(max_value);
-    if (depth == 0 || width <= 0 || height <= 0) return MICO_ERR_ARGS;
+    /* depth < 4: the Go tokeniser panics or emits empty chunks (rlecompressu16.go:57-67) */
+    if (depth < 4 || width <= 0 || height <= 0) return MICO_ERR_ARGS;
     uint16_t thr = (uint16_t)((1 << (depth - 1)) - 1);
     uint16_t delim = (uint16_t)((1 << depth) - 1);
     sink(ctx, max_value);
@@ -341,8 +342,10 @@ static int normalize_count2(fse_enc *s) {
         if (cnt <= low_one) { s->norm[i] = 1; distributed++; total -= cnt; continue; }
         s->norm[i] = not_yet;
     }
+    /* distributed >= 2^tl: Go divides by zero (==) or wraps to_distribute and then spins
+     * forever in the total==0 loop below (>) -- no behaviour to match, report it. */
+    if (distributed >= ((uint32_t)1 << tl)) return MICO_ERR_INTERNAL;
     uint32_t to_distribute = ((uint32_t)1 << tl) - distributed;
-    if (to_distribute == 0) return MICO_ERR_INTERNAL; /* Go: divide by zero panic */
     if ((total / to_distribute) > low_one) {
         low_one = (total * 3) / (to_distribute * 2);
         for (uint32_t i = 0; i < s->symbol_len; i++) {
@@ -351,6 +354,7 @@ static int normalize_count2(fse_enc *s) {
                 s->norm[i] = 1; distributed++; total -= cnt;
             }
         }
+        if (distributed >= ((uint32_t)1 << tl)) return MICO_ERR_INTERNAL;
         to_distribute = ((uint32_t)1 << tl) - distributed;
     }
     if (distributed == s->symbol_len + 1) {
@@ -361,6 +365,9 @@ static int normalize_count2(fse_enc *s) {
         return MICO_OK;
     }
     if (total == 0) {
+        int any = 0;
+        for (uint32_t i = 0; i < s->symbol_len; i++) if (s->norm[i] > 0) { any = 1; break; }
+        if (!any) return MICO_ERR_INTERNAL; /* Go: endless loop */
         for (uint32_t i = 0; to_distribute > 0; i = (i + 1) % s->symbol_len)
             if (s->norm[i] > 0) { to_distribute--; s->norm[i]++; }
         return MICO_OK;

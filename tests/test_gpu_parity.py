@@ -1,0 +1,166 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+libmic_hip.so and is compared bit-for-bit with the CPU oracle and the golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def _mr():
+    return np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
+
+
+def _ct():
+    return np.fromfile(os.path.join(GOLDEN, "CT_512_512_image.bin"), dtype="<u2").reshape(512, 512)
+
+
+@pytest.mark.parametrize("name", ["MR", "CT"])
+@pytest.mark.parametrize("ns", [2, 4, 8])
+def test_frame_matches_reference_c_golden(mic, mico, gpu_ready, name, ns):
+    """Bit-identical stream vs the reference C codec (tests/golden/golden.json) on the
+    reference's own test images; lossless round trip on the GPU."""
+    img = _mr() if name == "MR" else _ct()
+    rec = GOLD["streams"][f"{name}/{ns}"]
+    blob = mic.compress_single_frame(img, rec["width"], rec["height"], rec["max_value"], ns)
+    assert len(blob) == rec["size"]
+    assert f"{mico.fnv1a64(blob):016x}" == rec["fnv1a64"]
+    if name == "MR":
+        assert blob == open(os.path.join(GOLDEN, f"MR_256_256_{ns}state.mic"), "rb").read()
+    px = mic.decompress_single_frame(blob, rec["width"], rec["height"])
+    assert np.array_equal(px, img)
+
+
+@pytest.mark.parametrize("depth,w,h", [(12, 257, 63), (12, 640, 200), (16, 300, 211), (10, 129, 130), (8, 256, 256)])
+@pytest.mark.parametrize("ns", [2, 4, 8])
+def test_frame_matches_oracle_synthetic(mic, mico, synth, gpu_ready, depth, w, h, ns):
+    img = synth.xr_like(cols=w, rows=h, depth=depth, seed=depth * 7 + ns)
+    maxv = (1 << depth) - 1                      # caller-supplied maxValue > image max is legal
+    rc, want = mico.compress_single_frame(img, maxv, ns)
+    assert rc == 0
+    got = mic.compress_single_frame(img, w, h, maxv, ns)
+    assert got == want
+    assert np.array_equal(mic.decompress_single_frame(got, w, h), img)
+
+
+def test_decodes_every_flavour_the_oracle_writes(mic, mico, synth, gpu_ready):
+    """FSEDecompressU16Auto: 1-state (no prefix), FF02, FF04, FF84 and rANS FF08."""
+    img = synth.xr_like(cols=200, rows=150, depth=12, seed=5)
+    tok = mico.delta_rle_compress(img, 4095)
+    for ns in (1, 2, 4, 8, 108):
+        rc, blob = mico.fse_compress(tok, ns)
+        assert rc == 0
+        px = mic.decompress_single_frame(blob, 200, 150)
+        assert np.array_equal(px, img), ns
+
+
+def test_constant_frame_is_use_rle(mic, mico, gpu_ready):
+    """All tokens equal is impossible for a frame (delimiter + maxValue differ), but a constant
+    frame still exercises the long same-run path."""
+    img = np.full((64, 500), 1234, dtype=np.uint16)
+    rc, want = mico.compress_single_frame(img, 4095, 2)
+    if rc == 0:
+        assert mic.compress_single_frame(img, 500, 64, 4095, 2) == want
+    else:
+        with pytest.raises(mic.MicError) as e:
+            mic.compress_single_frame(img, 500, 64, 4095, 2)
+        assert e.value.code == rc
+
+
+def test_noise_frame_error_matches_oracle(mic, mico, synth, gpu_ready):
+    noise = (synth.hash_u64(512 * 512, 3) & np.uint64(0xFFFF)).astype(np.uint16).reshape(512, 512)
+    rc, want = mico.compress_single_frame(noise, 65535, 2)
+    if rc == 0:
+        assert mic.compress_single_frame(noise, 512, 512, 65535, 2) == want
+    else:
+        with pytest.raises(mic.MicError) as e:
+            mic.compress_single_frame(noise, 512, 512, 65535, 2)
+        assert e.value.code == rc
+
+
+def test_escape_path_and_long_runs(mic, mico, gpu_ready):
+    """|diff| >= T escapes (deltarlecompressu16.go:52-56) and run chunking at midCount
+    (rlecompressu16.go:57-67, midCount = 127 for depth 8)."""
+    img = np.zeros((96, 700), dtype=np.uint16)
+    img[:, ::3] = 255
+    img[40:60, :] = 7
+    img[60:, 100:600] = np.arange(500, dtype=np.uint16)[None, :] % 256
+    for maxv in (255, 511, 4095):
+        rc, want = mico.compress_single_frame(img, maxv, 2)
+        assert rc == 0
+        got = mic.compress_single_frame(img, 700, 96, maxv, 2)
+        assert got == want
+        assert np.array_equal(mic.decompress_single_frame(got, 700, 96), img)
+
+
+@pytest.mark.parametrize("strips", [1, 2, 4, 8])
+def test_pics_matches_oracle(mic, mico, gpu_ready, strips):
+    """CompressParallelStrips: global maxValue for every strip (parallelstrips.go:88)."""
+    img = _mr()
+    maxv = int(img.max())
+    rc, want = mico.pics_compress(img, maxv, strips, 2)
+    assert rc == 0
+    got = mic.compress_parallel_strips(img, 256, 256, maxv, strips)
+    assert got == want
+    px, w, h = mic.decompress_parallel_strips(got)
+    assert (w, h) == (256, 256) and np.array_equal(px, img)
+
+
+@pytest.mark.parametrize("ns", [4, 8])
+def test_pics_nstate_variants(mic, mico, gpu_ready, ns):
+    img = _mr()
+    rc, want = mico.pics_compress(img, int(img.max()), 8, ns)
+    assert rc == 0
+    assert mic.compress_parallel_strips(img, 256, 256, int(img.max()), 8, ns) == want
+    px, _, _ = mic.decompress_parallel_strips(want)
+    assert np.array_equal(px, img)
+
+
+def test_pics_clamp_bad_magic_truncation(mic, gpu_ready):
+    full = _mr()
+    img = full[:2].copy()
+    blob = mic.compress_parallel_strips(img, 256, 2, int(full.max()), 256)   # parallelstrips_test.go:119-145
+    assert mic.pics_info(blob)[2] == 2
+    px, w, h = mic.decompress_parallel_strips(blob)
+    assert (w, h) == (256, 2) and np.array_equal(px, img)
+    with pytest.raises(mic.MicError):
+        mic.decompress_parallel_strips(b"XXXX" + blob[4:])                   # :91-96
+    with pytest.raises(mic.MicError):
+        mic.decompress_parallel_strips(blob[:10])                            # :97-102
+
+
+def test_mic2_matches_oracle(mic, mico, synth, gpu_ready):
+    stack = synth.ct_stack(frames=6, size=128, depth=12, seed=21)
+    rc, want = mico.mic2_compress(stack, 4095, False)
+    assert rc == 0
+    got = mic.compress_multi_frame(stack, 128, 128, 4095)
+    assert got == want
+    assert np.array_equal(mic.decompress_multi_frame(got), stack)
+
+
+def test_batch_mixed_shapes(mic, mico, synth, gpu_ready):
+    frames = [synth.xr_like(cols=100 + 37 * i, rows=40 + 11 * i, depth=12, seed=30 + i) for i in range(7)]
+    res = mic.compress_batch(frames, [4095] * 7, 2)
+    for f, (st, blob, used) in zip(frames, res):
+        rc, want = mico.compress_single_frame(f, 4095, 2)
+        assert st == rc and blob == want
+    outs = mic.decompress_batch([b for _, b, _ in res], [(f.shape[1], f.shape[0]) for f in frames])
+    for f, (st, px) in zip(frames, outs):
+        assert st == 0 and np.array_equal(px, f)
+
+
+def test_corrupt_stream_is_an_error_not_a_hang(mic, mico, gpu_ready):
+    img = _mr()
+    rc, blob = mico.compress_single_frame(img, int(img.max()), 2)
+    bad = bytearray(blob)
+    bad[-1] = 0                                   # no end mark (bitreader.go:36-38)
+    with pytest.raises(mic.MicError):
+        mic.decompress_single_frame(bytes(bad), 256, 256)
+    with pytest.raises(mic.MicError):
+        mic.decompress_single_frame(blob[:40], 256, 256)
