@@ -145,13 +145,19 @@ def test_mic2_matches_oracle(mic, mico, synth, gpu_ready):
 
 
 def test_batch_mixed_shapes(mic, mico, synth, gpu_ready):
-    frames = [synth.xr_like(cols=100 + 37 * i, rows=40 + 11 * i, depth=12, seed=30 + i) for i in range(7)]
+    """One batch, ragged shapes; tiny noisy frames fail in the oracle (normaliser error) and
+    must fail with the same code on the GPU."""
+    frames = [synth.xr_like(cols=100 + 97 * i, rows=40 + 61 * i, depth=12, seed=30 + i) for i in range(7)]
     res = mic.compress_batch(frames, [4095] * 7, 2)
+    ok = []
     for f, (st, blob, used) in zip(frames, res):
         rc, want = mico.compress_single_frame(f, 4095, 2)
         assert st == rc and blob == want
-    outs = mic.decompress_batch([b for _, b, _ in res], [(f.shape[1], f.shape[0]) for f in frames])
-    for f, (st, px) in zip(frames, outs):
+        if rc == 0:
+            ok.append((f, blob))
+    assert len(ok) >= 4
+    outs = mic.decompress_batch([b for _, b in ok], [(f.shape[1], f.shape[0]) for f, _ in ok])
+    for (f, _), (st, px) in zip(ok, outs):
         assert st == 0 and np.array_equal(px, f)
 
 
