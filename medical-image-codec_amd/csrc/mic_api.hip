@@ -617,6 +617,14 @@ int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs, const uin
     if (rc) return rc;
     return mic_hip_session_decode_finish(s, h_status);
 }
+// debug probe (not part of the public header): raw result fields of unit i after a *_finish
+int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) {
+    if (!s || i < 0 || i >= s->n_last) return MIC_ERR_ARGS;
+    const MicUnit &u = s->h_units[(size_t)i];
+    out8[0] = u.ntok; out8[1] = u.blob_len; out8[2] = u.table_log; out8[3] = u.symbol_len;
+    out8[4] = u.max_count; out8[5] = u.hdr_len; out8[6] = u.zero_bits; out8[7] = u.flavour;
+    return MIC_OK;
+}
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {
     if (!s) return MIC_ERR_ARGS;
     s->timer.enabled = enabled != 0;

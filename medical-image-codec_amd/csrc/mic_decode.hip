@@ -76,6 +76,7 @@ struct BitR {
 __global__ void __launch_bounds__(64) k_dec_tans_serial(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (threadIdx.x != 0 || u.status != MICD_OK) return;
+    if (u.ntok != 0) return;                                           // a fast variant already decoded it
     const uint32_t tl = u.table_log;
     const uint32_t *dt = u.tt_nb;
     const uint16_t *ds = u.tab_sym;
@@ -170,10 +171,198 @@ __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
     }
 }
 
+
+// ==========================================================================================
+// Fast tANS decode: one wave per unit, decode table in LDS.
+//
+// The N states of an N-state stream (fse2state.go:203-308, fse4state.go:195-353,
+// fse8state.go:230-380, rans8state.go:221-412) share ONE reverse bitstream, so the chain
+//   state_k -> table entry -> (nbBits, newState) -> bits at the running position -> state_k'
+// is serial per stream; a stream cannot be split (the format has no resynchronisation points,
+// DESIGN.md §tANS).  The kernel therefore minimises the latency of one chain step, measured
+// with tools/ubench_chain.hip (dependent ds_read = 70 cycles, every dependent VALU op ~10):
+//   * all N look-ups of a group are issued together (one LDS round trip per N symbols);
+//   * the chain entry holds newState*4, nbBits and 32-nbBits ready-made: a state update is
+//     shift, shift-add (3 VALU ops for the second state of a pair), no clz / mask / multiply;
+//   * every lane computes the same values (no cross-lane traffic on the chain); the bit window
+//     and its refill bookkeeping sit in SGPRs, the refill is branch-free;
+//   * the stream is prefetched 64 dwords per load into a lane-distributed register buffer;
+//   * symbols are staged in LDS and leave as 256-byte coalesced stores.
+// LDS: chain[2^tl] u32 = newState*4 << 14 | (32-nbBits) << 8 | nbBits ; symt[2^tl] u16 ;
+//      stage[128] u16.   ZB = table has 0-bit entries (zeroBits, fsedecompressu16.go:214-216).
+// grid = units, block = 64, dynamic LDS = 6 << tl_hi + 256.
+template <int N, bool ZB>
+__global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
+    extern __shared__ uint32_t s_mem[];
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK) return;
+    const uint32_t flav = u.flavour;
+    if (flav == 1 || ((flav == 108) ? 8u : flav) != (uint32_t)N) return;
+    const uint32_t tl = u.table_log;
+    if (tl < tl_lo || tl > tl_hi) return;
+    if ((u.zero_bits != 0) != ZB) return;
+    if (u.ntok != 0) return;                                            // already decoded by another variant
+    const uint32_t lane = threadIdx.x;
+    const uint32_t size = 1u << tl;
+    uint32_t *chain = s_mem;
+    uint16_t *symt = (uint16_t *)(s_mem + size);
+    uint32_t *stage = s_mem + size + size / 2;                          // 64 dwords = 128 symbols
+    {
+        const uint32_t *dt = u.tt_nb; const uint16_t *ds = u.tab_sym;
+        for (uint32_t p = lane; p < size; p += 64) {
+            uint32_t e = dt[p];                                         // newState | nbBits << 16
+            uint32_t nb = e >> 16;
+            chain[p] = ((e & 0xFFFF) << 16) | ((32u - nb) << 8) | nb;
+            symt[p] = ds[p];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = u.count;
+    uint16_t *out = u.tok;
+    if (u.bits_off >= u.comp_len) { if (lane == 0) u.status = MICD_ERR_CORRUPT; return; }
+    const uint8_t *bs = u.comp_in + u.bits_off;
+    const uint32_t len = u.comp_len - u.bits_off;
+    // readfirstlane: the byte comes back in a VGPR; everything derived from it (cursor, window,
+    // refill bookkeeping) is wave-uniform and must live in SGPRs / run on the scalar unit
+    const uint32_t last = __builtin_amdgcn_readfirstlane((uint32_t)bs[len - 1]);
+    if (last == 0) { if (lane == 0) u.status = MICD_ERR_CORRUPT; return; }  // bitreader.go:36-38
+    const uint64_t total_bits = 8ull * (len - 1) + (uint32_t)(31 - __clz(last));
+    // 4-byte aligned dword grid under the stream: grid bit 0 = LSB of g[0]
+    const uintptr_t addr = (uintptr_t)bs;
+    const uint32_t sb = (uint32_t)(addr & 3);
+    const uint32_t *g = (const uint32_t *)(addr - sb);
+    const uint64_t cur = total_bits + 8ull * sb;                        // unread bits are grid bits [8*sb, cur)
+    const int64_t top_dw = (int64_t)((cur - 1) >> 5);                   // dword holding the top unread bit
+    int64_t di = top_dw;
+    // lane-distributed stream buffer: buf_a = the 64 dwords of block di>>6, buf_b = the block below
+    auto load_blk = [&](int64_t b) -> uint32_t {
+        int64_t idx = b * 64 + (int64_t)lane;
+        return (b >= 0 && idx <= top_dw) ? g[idx] : 0u;
+    };
+    uint32_t buf_a = load_blk(di >> 6), buf_b = load_blk((di >> 6) - 1);
+    uint64_t W = 0; uint32_t avail = 0;
+    uint64_t consumed = 0;
+    // take T (<= 32, uniform) bits off the window and top it up to >= 32 valid bits; branch-free
+    // except when the register buffer runs out (every 64 refills)
+    auto advance = [&](uint32_t T) {
+        W <<= T; avail -= T; consumed += T;
+        const uint32_t nd = __builtin_amdgcn_readlane(buf_a, (int)((uint32_t)di & 63u));
+        const bool need = avail < 32;
+        const uint64_t add = (uint64_t)nd << ((32u - avail) & 63u);
+        W |= need ? add : 0ull;
+        avail += need ? 32u : 0u;
+        if (need) {
+            if (((uint32_t)di & 63u) == 0u) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 2); }
+            di--;
+        }
+    };
+    {   // prime the window: the top dword holds 1..32 valid bits
+        const uint32_t top = (uint32_t)(cur - 32ull * (uint64_t)di);
+        W = (uint64_t)__builtin_amdgcn_readlane(buf_a, (int)((uint32_t)di & 63u)) << (64 - top);
+        avail = top;
+        if (((uint32_t)di & 63u) == 0u) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 2); }
+        di--;
+        advance(0);
+    }
+    uint32_t st[N];                                                     // states as LDS byte offsets (state*4)
+    // initial states: state 0 first, tl bits each (fse2state.go:210-212)
+#pragma unroll
+    for (int p = 0; p < N; p += 2) {
+        const uint32_t hi = (uint32_t)(W >> 32);
+        st[p] = __builtin_amdgcn_ubfe(hi, 32u - tl, tl) << 2;
+        st[p + 1] = __builtin_amdgcn_ubfe(hi, 32u - 2u * tl, tl) << 2;
+        advance(2u * tl);
+    }
+    const char *chain_b = (const char *)chain;
+    const char *symt_b = (const char *)symt;
+    const uint32_t groups = count / N;
+    uint32_t i = 0;
+#ifdef MIC_STAMP
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t gidx = 0; gidx < groups; gidx++, i += N) {
+        uint32_t e[N], sy[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            e[k] = *(const uint32_t *)(chain_b + st[k]);
+            sy[k] = *(const uint16_t *)(symt_b + (st[k] >> 1));
+        }
+#pragma unroll
+        for (int p = 0; p < N; p += 2) {
+            const uint32_t hi = (uint32_t)(W >> 32);
+            const uint32_t nb0 = e[p] & 0xFF, nb1 = e[p + 1] & 0xFF;
+            uint32_t b0, b1;
+            if (ZB) {
+                b0 = __builtin_amdgcn_ubfe(hi, 32u - nb0, nb0);
+                b1 = __builtin_amdgcn_ubfe(hi, 32u - nb0 - nb1, nb1);
+            } else {                                                    // nbBits >= 1: plain shifts
+                b0 = hi >> ((e[p] >> 8) & 0xFF);
+                b1 = (hi << nb0) >> ((e[p + 1] >> 8) & 0xFF);
+            }
+            st[p] = (b0 << 2) + ((e[p] >> 16) << 2);
+            st[p + 1] = (b1 << 2) + ((e[p + 1] >> 16) << 2);
+            stage[((i & 127u) >> 1) + (p >> 1)] = sy[p] | (sy[p + 1] << 16);
+            advance(__builtin_amdgcn_readfirstlane(nb0 + nb1));
+        }
+        if (((i + N) & 127u) == 0) {                                    // 128 symbols staged: one 256-B store
+            ((uint32_t *)out)[((i + N - 128u) >> 1) + lane] = stage[lane];
+        }
+    }
+#ifdef MIC_STAMP
+    if (lane == 0) { u.max_count = (uint32_t)(__builtin_amdgcn_s_memtime() - t_loop0); u.hdr_len = groups; }
+#endif
+    // tail: count % N symbols, states 0 .. r-1 in order (fse2state.go:293-305)
+    const uint32_t r = count - i;
+    if (r) {
+        uint32_t e[N], sy[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            e[k] = *(const uint32_t *)(chain_b + st[k]);
+            sy[k] = *(const uint16_t *)(symt_b + (st[k] >> 1));
+        }
+#pragma unroll
+        for (int p = 0; p < N; p += 2) {
+            const uint32_t nb0 = ((uint32_t)p < r) ? (e[p] & 0xFF) : 0u;
+            const uint32_t nb1 = ((uint32_t)p + 1 < r) ? (e[p + 1] & 0xFF) : 0u;
+            stage[((i & 127u) >> 1) + (p >> 1)] = sy[p] | (sy[p + 1] << 16);
+            advance(__builtin_amdgcn_readfirstlane(nb0 + nb1));
+        }
+    }
+    // flush the partially filled stage (symbols [i & ~127, count))
+    {
+        const uint32_t base = i & ~127u;
+        const uint16_t *st16 = (const uint16_t *)stage;
+        for (uint32_t k = lane; base + k < count && k < 128; k += 64) out[base + k] = st16[k];
+    }
+    if (lane == 0) {
+        if (consumed > total_bits) u.status = MICD_ERR_CORRUPT;         // bitreader.go:113-120
+        else u.ntok = count;
+    }
+}
+
+template <int N, bool ZB>
+static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (6u << 13) + 256, stream, d_units, 5u, 13u);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (6u << 14) + 256, stream, d_units, 14u, 14u);
+}
+
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
-    (void)variant;
     if (t) t->mark("k_dec_tables");
     hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(64), 0, stream, d_units);
+    if (variant != 100) {
+        if (t) t->mark("k_dec_tans_lds");
+        launch_tans_lds<2, false>(d_units, n, stream);
+        launch_tans_lds<4, false>(d_units, n, stream);
+        launch_tans_lds<8, false>(d_units, n, stream);
+        launch_tans_lds<2, true>(d_units, n, stream);
+        launch_tans_lds<4, true>(d_units, n, stream);
+        launch_tans_lds<8, true>(d_units, n, stream);
+    }
     if (t) t->mark("k_dec_tans_serial");
     hipLaunchKernelGGL(k_dec_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_dec_pixels_serial");
