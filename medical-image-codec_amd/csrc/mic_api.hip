@@ -78,7 +78,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct mic_hip_session {
     int max_units = 0; size_t max_px = 0;
     hipStream_t stream = nullptr;
-    DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets;
+    DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
     DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
     std::vector<MicUnit> h_units;
     std::vector<uint64_t> h_off;
@@ -86,7 +86,7 @@ struct mic_hip_session {
     int variant = 0;                        // kernel generation selector (0 = default)
     MicTimer timer;
     std::vector<std::string> t_names; std::vector<float> t_ms;
-    size_t tok_stride = 0, blob_stride = 0;
+    size_t tok_stride = 0, blob_stride = 0, seg_stride = 0, sym_stride = 0, flag_stride = 0;
 
     int ensure(int n, size_t px) {
         if (!stream) HIP_TRY(hipStreamCreate(&stream));
@@ -94,6 +94,9 @@ struct mic_hip_session {
         int nn = std::max(n, max_units); size_t pp = std::max(px, max_px);
         tok_stride = align_up(tok_cap_for(pp) * 2, 256);
         blob_stride = align_up(blob_cap_for(pp), 256);
+        seg_stride = align_up((2 * pp + 8) * 8, 256);
+        sym_stride = align_up(tok_cap_for(pp) * 2, 256);
+        flag_stride = align_up(pp / 8 + 8, 256);
         int rc;
         if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
         if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
@@ -106,6 +109,9 @@ struct mic_hip_session {
         if ((rc = cumul.reserve((kSym + 64) * 4 * (size_t)nn))) return rc;
         if ((rc = blob.reserve(blob_stride * (size_t)nn))) return rc;
         if ((rc = offsets.reserve(8 * ((size_t)nn + 1)))) return rc;
+        if ((rc = seg.reserve(seg_stride * (size_t)nn))) return rc;
+        if ((rc = sym.reserve(sym_stride * (size_t)nn))) return rc;
+        if ((rc = flags.reserve(flag_stride * (size_t)nn))) return rc;
         max_units = nn; max_px = pp;
         return MIC_OK;
     }
@@ -121,9 +127,14 @@ struct mic_hip_session {
         u.cumul = (int32_t *)cumul.p + (kSym + 64) * (size_t)i;
         u.blob = (uint8_t *)blob.p + blob_stride * (size_t)i;
         u.blob_cap = (uint32_t)std::min<size_t>(blob_cap_for(max_px), 0xFFFFFFF0u);
+        u.seg = (uint2 *)((char *)seg.p + seg_stride * (size_t)i);
+        u.seg_cap = (uint32_t)std::min<size_t>(2 * max_px + 8, 0xFFFFFFF0u);
+        u.sym = (uint16_t *)((char *)sym.p + sym_stride * (size_t)i);
+        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
+        u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     void release() {
-        DevBuf *all[] = { &units, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &io_px, &io_comp };
+        DevBuf *all[] = { &units, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp };
         for (DevBuf *b : all) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -212,6 +223,7 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
         u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
     }
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, &s->timer);
     HIP_TRY(hipGetLastError());
@@ -232,7 +244,7 @@ int session_decode_finish(mic_hip_session *s, int32_t *h_status) {
 // Units are processed in sub-batches that keep the workspace under a fixed budget.
 constexpr size_t kWorkspaceBudget = (size_t)24 << 30;
 
-size_t unit_ws_bytes(size_t px) { return tok_cap_for(px) * 2 + blob_cap_for(px) + kSym * 4 * 6 + kSym * 2 + 4096; }
+size_t unit_ws_bytes(size_t px) { return tok_cap_for(px) * 4 + blob_cap_for(px) + (2 * px + 8) * 8 + px / 8 + kSym * 4 * 6 + kSym * 2 + 8192; }
 
 int compress_batch_locked(mic_hip_enc_job *jobs, int njobs) {
     mic_hip_session *s = &g_default;
@@ -335,6 +347,7 @@ int decompress_batch_locked(mic_hip_dec_job *jobs, int njobs) {
             u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
         }
         HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
         mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr);
         HIP_TRY(hipGetLastError());
         s->n_last = n;
