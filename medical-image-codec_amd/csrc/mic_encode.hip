@@ -117,6 +117,279 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Parallel Delta(avg) + RLE tokeniser: one work-group of 1024 threads per unit.
+//
+// The reference tokeniser (rlecompressu16.go:24-83) is a serial state machine, but its output
+// is a pure function of the maximal runs of the delta-symbol stream x[0..M) (x[0] = maxValue):
+//   * a maximal run of L >= 3 equal symbols ("same-run") is emitted as (c, v) every c symbols
+//     from its (c+3)-th symbol on, then (rem, v) with rem = (L-3) % c + 3 when it ends, where
+//     c = midCount - 3 (the flush at len(b) >= midCount-1 keeps two symbols buffered);
+//   * the symbols between same-runs ("diff stretch") are emitted as literal chunks of c symbols,
+//     header midCount + chunk length in front; a chunk boundary needs two more symbols behind
+//     it (they sit in the reference's buffer when the flush fires), so the last two symbols of
+//     the whole stream never open a chunk.
+// Every symbol can therefore compute the tokens it is responsible for from x[i-2..i+3], its
+// index inside its run / stretch (segmented max-scans) and a prefix sum of token counts.
+// Symbols are produced 2048 pixels at a time (1 or 2 symbols per pixel, prefix-summed) into an
+// LDS window and tokenised with a delay of 3 symbols so the look-ahead is always present.
+#define TK_THREADS 1024
+#define TK_WAVES 16
+#define TK_PPT 2
+#define TK_SPT 4
+#define TK_WIN (TK_THREADS * TK_SPT)
+
+__device__ __forceinline__ uint32_t tk_wave_incl_add(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v += o; }
+    return v;
+}
+__device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v = max(v, o); }
+    return v;
+}
+
+__global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
+    MicUnit &u = units[blockIdx.x];
+    __shared__ uint16_t xs[TK_WIN + 16];          // [0..5] = 6 symbols before the tile, [6..] = new symbols
+    __shared__ uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
+    __shared__ uint32_t s_ovf;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; }
+    const int depth = mic_len16(u.max_value);
+    if (u.w <= 0 || u.h <= 0) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
+    if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
+    const uint32_t thr = (1u << (depth - 1)) - 1;
+    const uint32_t delim = (1u << depth) - 1;
+    const uint32_t mid = (1u << (depth - 1)) - 1;          // Len16(delim) == depth
+    const uint32_t c = mid - 3;
+    const uint16_t *in = u.px_in;
+    uint16_t *tok = u.tok;
+    const uint32_t cap = u.tok_cap;
+    const uint32_t W = (uint32_t)u.w;
+    const uint32_t npx = W * (uint32_t)u.h;
+    const uint32_t ntiles = (npx + TK_THREADS * TK_PPT - 1) / (TK_THREADS * TK_PPT);
+    // carried, work-group uniform state
+    uint32_t g0 = 1;                 // symbols generated so far; symbol 0 = maxValue is pre-seeded in the halo
+    uint32_t outp = 1;               // tokens written so far; tok[0] = delimiter (rlecompressu16.go:21)
+    uint32_t run1 = 0, str1 = 0;     // index+1 of the first symbol of the current run / diff stretch (0 = none)
+    uint32_t last_same = 0;
+    if (tid == 0) { if (cap > 0) tok[0] = (uint16_t)delim; xs[5] = u.max_value; }
+    __syncthreads();
+    for (uint32_t tile = 0; tile <= ntiles; tile++) {
+        const bool flush = tile == ntiles;
+        // ---- A: delta symbols of this tile's pixels (deltarlecompressu16.go:31-61) ----------
+        uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0;
+        if (!flush) {
+            const uint32_t gbase = tile * (TK_THREADS * TK_PPT) + tid * TK_PPT;
+#pragma unroll
+            for (int k = 0; k < TK_PPT; k++) {
+                const uint32_t g = gbase + k;
+                if (g < npx) {
+                    const uint32_t y = g / W, x = g - y * W;
+                    int32_t prev = 0;
+                    if (x > 0) prev = in[g - 1];
+                    if (y > 0) prev += in[g - W];
+                    if (x > 0 && y > 0) prev >>= 1;
+                    const uint32_t val = in[g];
+                    const int32_t diff = (int32_t)val - prev;
+                    const uint32_t ad = (uint32_t)(diff < 0 ? -diff : diff) & 0xFFFF;
+                    if (ad >= thr) { ls[cnt++] = delim; ls[cnt++] = val; }
+                    else ls[cnt++] = (uint32_t)((int32_t)thr + diff) & 0xFFFF;
+                }
+            }
+        }
+        const uint32_t incl = tk_wave_incl_add(cnt, lane);
+        if (lane == 63) s_cnt[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, n = 0;
+#pragma unroll
+        for (int wv = 0; wv < TK_WAVES; wv++) { const uint32_t v = s_cnt[wv]; if ((uint32_t)wv < wave) woff += v; n += v; }
+        {
+            const uint32_t off = 6 + woff + incl - cnt;
+            for (uint32_t k = 0; k < cnt; k++) xs[off + k] = (uint16_t)ls[k];
+        }
+        __syncthreads();
+        const uint32_t g1 = g0 + n;
+        // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3]
+        const uint32_t nwin = flush ? 3u : n;
+        // ---- B: per-position facts + per-thread run / stretch starts --------------------------
+        uint32_t my_run = 0, my_str = 0;            // latest start (index+1) inside this thread's positions
+        uint32_t same_bits = 0;                     // bit q = isSame, bit 8+q = run start, 16+q = stretch start
+        uint32_t prev_same_in = 0;                  // isSame of the symbol before this thread's first position
+        {
+            // isSame of position p-1 for the thread's first position: recompute from the window
+            // (needs x[i-3], present for p >= 1 because the halo holds 3 already-processed symbols)
+            const uint32_t p0 = tid * TK_SPT;
+            if (p0 == 0) prev_same_in = last_same;
+            else if (p0 <= nwin) {
+                const int64_t i = (int64_t)g0 - 3 + p0 - 1;          // symbol before the first position
+                if (i >= 0) {
+                    const uint32_t idx = p0 - 1 + 3;
+                    const bool em3 = (i - 3 >= 0) && idx >= 3 && xs[idx - 3] == xs[idx - 2];
+                    const bool em2 = (i - 2 >= 0) && xs[idx - 2] == xs[idx - 1];
+                    const bool em1 = (i - 1 >= 0) && xs[idx - 1] == xs[idx];
+                    const bool ep1 = xs[idx] == xs[idx + 1];          // position p0 exists (p0 < nwin or flush tail)
+                    const bool ep2 = ((flush ? (i + 2 < (int64_t)g1) : true)) && xs[idx + 1] == xs[idx + 2];
+                    (void)em3;
+                    prev_same_in = ((em2 && em1) || (em1 && ep1) || (ep1 && ep2)) ? 1u : 0u;
+                }
+            }
+        }
+        uint32_t prev_same = prev_same_in;
+#pragma unroll
+        for (int q = 0; q < TK_SPT; q++) {
+            const uint32_t p = tid * TK_SPT + q;
+            if (p < nwin) {
+                const int64_t i = (int64_t)g0 - 3 + p;
+                if (i >= 0) {
+                    const uint32_t idx = p + 3;
+                    const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
+                    const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
+                    const bool em2 = (i - 2 >= 0) && xs[idx - 2] == xs[idx - 1];
+                    const bool em1 = (i - 1 >= 0) && xs[idx - 1] == xs[idx];
+                    const bool ep1 = ex1 && xs[idx] == xs[idx + 1];
+                    const bool ep2 = ex2 && xs[idx + 1] == xs[idx + 2];
+                    const bool same = (em2 && em1) || (em1 && ep1) || (ep1 && ep2);
+                    const bool rs = !em1;                               // first symbol of a run
+                    const bool ss = !same && (i == 0 || prev_same);     // first symbol of a diff stretch
+                    if (same) same_bits |= 1u << q;
+                    if (rs) { same_bits |= 1u << (8 + q); my_run = (uint32_t)i + 1; }
+                    if (ss) { same_bits |= 1u << (16 + q); my_str = (uint32_t)i + 1; }
+                    prev_same = same ? 1u : 0u;
+                }
+            }
+        }
+        // exclusive max-scan of the thread-latest starts (positions grow with the thread index)
+        const uint32_t run_incl = tk_wave_incl_max(my_run, lane), str_incl = tk_wave_incl_max(my_str, lane);
+        if (lane == 63) { s_run[wave] = run_incl; s_str[wave] = str_incl; }
+        uint32_t run_in = __shfl_up(run_incl, 1), str_in = __shfl_up(str_incl, 1);
+        if (lane == 0) { run_in = 0; str_in = 0; }
+        __syncthreads();
+        uint32_t run_tot = run1, str_tot = str1;
+#pragma unroll
+        for (int wv = 0; wv < TK_WAVES; wv++) {
+            const uint32_t a = s_run[wv], b = s_str[wv];
+            if ((uint32_t)wv < wave) { run_in = max(run_in, a); str_in = max(str_in, b); }
+            run_tot = max(run_tot, a); str_tot = max(str_tot, b);
+        }
+        run_in = max(run_in, run1); str_in = max(str_in, str1);
+        // ---- C: tokens owned by each position ---------------------------------------------------
+        uint32_t tc[TK_SPT]; uint32_t kk[TK_SPT]; uint32_t tsum = 0;
+        {
+            uint32_t rcur = run_in, scur = str_in;
+#pragma unroll
+            for (int q = 0; q < TK_SPT; q++) {
+                const uint32_t p = tid * TK_SPT + q;
+                tc[q] = 0; kk[q] = 0;
+                if (p < nwin) {
+                    const int64_t i = (int64_t)g0 - 3 + p;
+                    if (i >= 0) {
+                        const uint32_t idx = p + 3;
+                        if (same_bits & (1u << (8 + q))) rcur = (uint32_t)i + 1;
+                        if (same_bits & (1u << (16 + q))) scur = (uint32_t)i + 1;
+                        const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
+                        const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
+                        if (same_bits & (1u << q)) {
+                            const uint32_t k = (uint32_t)i + 1 - rcur + 1;          // 1-based index in the run
+                            const bool last = !ex1 || xs[idx] != xs[idx + 1];
+                            uint32_t t = 0;
+                            if (k > 3 && (k - 3) % c == 0) t += 2;
+                            if (last) t += 2;
+                            tc[q] = t; kk[q] = k;
+                        } else {
+                            const uint32_t j = (uint32_t)i + 1 - scur + 1;          // 1-based index in the stretch
+                            const bool starts = (j == 1) || ((j - 1) % c == 0 && ex2);
+                            tc[q] = starts ? 2u : 1u; kk[q] = j;
+                        }
+                        tsum += tc[q];
+                    }
+                }
+            }
+        }
+        const uint32_t tincl = tk_wave_incl_add(tsum, lane);
+        if (lane == 63) s_tc[wave] = tincl;
+        __syncthreads();
+        uint32_t toff = 0, ttot = 0;
+#pragma unroll
+        for (int wv = 0; wv < TK_WAVES; wv++) { const uint32_t v = s_tc[wv]; if ((uint32_t)wv < wave) toff += v; ttot += v; }
+        // ---- D: write ----------------------------------------------------------------------------
+        {
+            uint32_t pos = outp + toff + tincl - tsum;
+            bool ovf = false;
+#pragma unroll
+            for (int q = 0; q < TK_SPT; q++) {
+                const uint32_t p = tid * TK_SPT + q;
+                if (tc[q] == 0 && !(p < nwin)) continue;
+                if (!(p < nwin)) continue;
+                const int64_t i = (int64_t)g0 - 3 + p;
+                if (i < 0) continue;
+                const uint32_t idx = p + 3;
+                const uint32_t xv = xs[idx];
+                const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
+                const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
+                const bool ex3 = flush ? (i + 3 < (int64_t)g1) : true;
+                if (same_bits & (1u << q)) {
+                    const uint32_t k = kk[q];
+                    if (k > 3 && (k - 3) % c == 0) {
+                        if (pos + 1 < cap) { tok[pos] = (uint16_t)c; tok[pos + 1] = (uint16_t)xv; } else ovf = true;
+                        pos += 2;
+                    }
+                    const bool last = !ex1 || xv != xs[idx + 1];
+                    if (last) {
+                        const uint32_t rem = (k - 3) % c + 3;
+                        if (pos + 1 < cap) { tok[pos] = (uint16_t)rem; tok[pos + 1] = (uint16_t)xv; } else ovf = true;
+                        pos += 2;
+                    }
+                } else {
+                    const uint32_t j = kk[q];
+                    const uint32_t jm = (j - 1) % c;
+                    const bool starts = (j == 1) || (jm == 0 && ex2);
+                    const uint32_t lit = pos + (starts ? 1u : 0u);
+                    if (lit < cap) tok[lit] = (uint16_t)xv; else ovf = true;
+                    pos += starts ? 2u : 1u;
+                    // does the chunk end here?  next symbol: end of stream / start of a same-run / opens a chunk
+                    bool same_next;
+                    if (!ex1) same_next = false;
+                    else if (xs[idx + 1] == xv) same_next = false;        // a run of 2 (this symbol is not in a same-run)
+                    else same_next = ex3 && xs[idx + 1] == xs[idx + 2] && xs[idx + 2] == xs[idx + 3];
+                    const bool next_starts = (j % c == 0) && ex3;
+                    if (!ex1 || same_next || next_starts) {
+                        uint32_t qlen = jm + 1;
+                        // boundary suppressed for the last two symbols of the stream: they extend the previous chunk
+                        if (j - jm > 1 && !((i - (int64_t)jm + 2) < (int64_t)g1) && flush) qlen += c;
+                        if (lit >= qlen && lit - qlen < cap) tok[lit - qlen] = (uint16_t)(mid + qlen); else ovf = true;
+                    }
+                }
+            }
+            if (ovf) s_ovf = 1;
+        }
+        // ---- E: carry --------------------------------------------------------------------------------
+        outp += ttot;
+        run1 = run_tot; str1 = str_tot;
+        // isSame of the last processed symbol
+        {
+            __syncthreads();
+            if (nwin > 0) {
+                const uint32_t pl = nwin - 1;
+                if (tid == pl / TK_SPT) s_cnt[0] = (same_bits >> (pl % TK_SPT)) & 1;
+            }
+            uint16_t keep = 0;
+            if (tid < 6) keep = xs[n + tid];
+            __syncthreads();
+            if (nwin > 0 && ((int64_t)g0 - 3 + (int64_t)nwin - 1) >= 0) last_same = s_cnt[0];
+            if (tid < 6) xs[tid] = keep;
+            __syncthreads();
+        }
+        g0 = g1;
+    }
+    if (tid == 0) {
+        if (s_ovf || outp > cap) u.status = MICD_ERR_CAPACITY;
+        else u.ntok = outp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Histogram of the token stream.  grid = (blocks_per_unit, units), block = 256.
 // hist must be zero on entry (the launcher memsets the workspace slab).
 __global__ void __launch_bounds__(256) k_enc_hist(MicUnit *units) {
@@ -282,9 +555,13 @@ __global__ void __launch_bounds__(1024) k_scan_lens(const MicUnit *units, int n,
 // ------------------------------------------------------------------------------------------
 // launchers
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
-    (void)variant;
-    if (t) t->mark("k_enc_tokens_serial");
-    hipLaunchKernelGGL(k_enc_tokens_serial, dim3(n), dim3(64), 0, stream, d_units);
+    if (variant == 100) {
+        if (t) t->mark("k_enc_tokens_serial");
+        hipLaunchKernelGGL(k_enc_tokens_serial, dim3(n), dim3(64), 0, stream, d_units);
+    } else {
+        if (t) t->mark("k_enc_tokens_wg");
+        hipLaunchKernelGGL(k_enc_tokens_wg, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+    }
     if (t) t->mark("k_enc_hist");
     hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
     if (t) t->mark("k_enc_tables");
