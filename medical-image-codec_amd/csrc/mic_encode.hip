@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
     if (u.blob_cap < 6 + 8) { u.status = MICD_ERR_CAPACITY; return; }
     rc = mic_write_ncount(u.norm, u.symbol_len, u.table_log, u.blob + 6, u.blob_cap - 6, &u.hdr_len);
     if (rc) { u.status = rc; return; }
+    for (int k = 0; k < 8; k++) u.blob[6 + u.hdr_len + k] = 0;   // k_enc_tans_wg ORs into the first stream word
     rc = mic_build_ctable(u);
     if (rc) { u.status = rc; return; }
 }
@@ -468,6 +469,7 @@ struct BitW {
 __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (threadIdx.x != 0 || u.status != MICD_OK) return;
+    if (u.nstates_used != 0) return;                                      // k_enc_tans_wg already wrote it
     const uint32_t n = u.ntok;
     const uint16_t *src = u.tok;
     const uint32_t tl = u.table_log;
@@ -514,6 +516,193 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
         if (lanes == 1) return;
         if (rc == MICD_ERR_CAPACITY) return;
         u.status = MICD_OK;                                             // try the next flavour
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Parallel N-state tANS encode: one work-group of 1024 threads per unit.
+//
+// Chain k (k = index mod N) is a serial walk  state -> stateTable[(state >> nb) + dFind[sym]]
+// from the last symbol to the first (fsecompressu16.go:95-100, fse2state.go:122-199).  After a
+// symbol whose normalised count is v the state is one of only v table slots, so two walks over
+// the same symbols started from different states merge after a few dozen symbols (measured:
+// mean 40..120).  That makes the chain splittable, exactly:
+//   1. every thread walks its segment of a chain from a guessed start state and records the
+//      state in front of every symbol;
+//   2. every thread re-walks the head of its segment from the true end state of the previous
+//      segment until it meets its own recorded states; segments whose end state changed make
+//      their successor repeat the step -- iterate to the fixed point (usually two rounds,
+//      at worst one round per segment, which is the serial walk);
+//   3. the bits of symbol i are (state & mask(nb), nb); a prefix sum of nb over the emission
+//      order (last symbol first, bitwriter.go) gives every thread its bit offset, and each thread
+//      packs its range into 32-bit words.  A word is stored by the thread that owns its first
+//      bit; the threads that only reach into a word OR their bits in after a barrier.
+// Then the final states (last lane first), the end mark, the size gate and the prefix bytes,
+// and the N -> N/2 -> ... -> 1 fallback chain of multiframecompress.go:15-93.
+// LDS: stateTable as u16 (state - 2^tl).  grid = units, block = 1024, dynamic LDS = 2 << tl.
+#define TE_THREADS 1024
+#define TE_WAVES 16
+
+__global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
+    extern __shared__ uint16_t s_stab[];
+    __shared__ uint32_t s_E[2][TE_THREADS];
+    __shared__ uint32_t s_scan[TE_WAVES];
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.nstates_used != 0) return;
+    const uint32_t tl = u.table_log;
+    if (tl < tl_lo || tl > tl_hi) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = u.ntok;
+    const uint32_t size = 1u << tl;
+    const uint16_t *src = u.tok;
+    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
+    uint16_t *stv = u.sym;                                   // state - 2^tl in front of every token
+    if (u.sym_cap < n) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
+    for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
+    __syncthreads();
+    const uint32_t hdr_len = u.hdr_len;
+    uint8_t *bits_base = u.blob + 6 + hdr_len;               // the bitstream sits right behind the NCount header
+    const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 3);
+    uint32_t *words = (uint32_t *)(bits_base - lead);        // aligned word grid; grid bit 8*lead = stream bit 0
+    const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
+
+    for (uint32_t lanes = u.nstates; lanes >= 1; lanes >>= 1) {
+        // length gates: fse8state.go:32, fse4state.go:25, fse2state.go:23, fsecompressu16.go:20
+        int rc = MICD_OK;
+        if (n <= lanes - 1 || n <= 1) rc = MICD_ERR_INCOMPRESSIBLE;
+        else if (n <= 2 && lanes <= 2) rc = MICD_ERR_INTERNAL;                   // "src too small"
+        uint32_t total_bytes = 0;
+        if (rc == MICD_OK) {
+            // ---- 1. speculative walks --------------------------------------------------------
+            const uint32_t tpc = TE_THREADS / lanes;           // threads per chain
+            const uint32_t ch = tid % lanes, sg = tid / lanes; // chain, segment
+            const uint32_t m = (n > ch) ? (n - ch + lanes - 1) / lanes : 0;      // symbols on this chain
+            const uint32_t L = ((n + lanes - 1) / lanes + tpc - 1) / tpc;        // segment length (uniform)
+            const uint32_t r0 = min(m, sg * L), r1 = min(m, r0 + L);
+            // chain position r (0 = encoded first) <-> token index ch + lanes*(m-1-r)
+            uint32_t state = size;
+            for (uint32_t r = r0; r < r1; r++) {
+                const uint32_t idx = ch + lanes * (m - 1 - r);
+                const uint32_t sy = src[idx];
+                stv[idx] = (uint16_t)(state - size);
+                const uint32_t nb = (state + tt_nb[sy]) >> 16;
+                state = size + s_stab[(int32_t)(state >> nb) + tt_find[sy]];
+            }
+            s_E[0][tid] = state;
+            uint32_t assumed = size;                            // start state the recorded walk assumed
+            // ---- 2. fix-up rounds ---------------------------------------------------------------
+            uint32_t cur = 0;
+            for (uint32_t round = 0; round < TE_THREADS; round++) {
+                __syncthreads();
+                int changed = 0;
+                uint32_t e_out = s_E[cur][tid];
+                if (sg > 0) {
+                    const uint32_t e_prev = s_E[cur][tid - lanes];
+                    if (e_prev != assumed) {
+                        assumed = e_prev;
+                        uint32_t st2 = e_prev; uint32_t r = r0;
+                        for (; r < r1; r++) {
+                            const uint32_t idx = ch + lanes * (m - 1 - r);
+                            if ((uint32_t)stv[idx] + size == st2) break;          // merged with the recorded walk
+                            const uint32_t sy = src[idx];
+                            stv[idx] = (uint16_t)(st2 - size);
+                            const uint32_t nb = (st2 + tt_nb[sy]) >> 16;
+                            st2 = size + s_stab[(int32_t)(st2 >> nb) + tt_find[sy]];
+                        }
+                        // an empty segment (r0 == r1) just hands the state on; it never asks for a round
+                        if (r == r1 && st2 != e_out) { e_out = st2; changed = (r1 > r0) ? 1 : 0; }
+                    }
+                }
+                s_E[cur ^ 1][tid] = e_out;
+                cur ^= 1;
+                if (!__syncthreads_or(changed)) break;
+            }
+            __syncthreads();
+            __threadfence_block();
+            // final state of every chain = end state of its last segment
+            // ---- 3. bit offsets ---------------------------------------------------------------------
+            const uint32_t R = (n + TE_THREADS - 1) / TE_THREADS;
+            const uint32_t hi = (tid * R < n) ? n - tid * R : 0;       // tokens [lo, hi), emitted from hi-1 down
+            const uint32_t lo = (hi > R) ? hi - R : 0;
+            uint32_t mybits = 0;
+            for (uint32_t idx = hi; idx > lo; idx--) {
+                const uint32_t st = (uint32_t)stv[idx - 1] + size;
+                mybits += (st + tt_nb[src[idx - 1]]) >> 16;
+            }
+            uint32_t incl = tk_wave_incl_add(mybits, lane);
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            uint32_t woff = 0, sym_bits = 0;
+#pragma unroll
+            for (int wv = 0; wv < TE_WAVES; wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
+            const uint64_t gstart = 8ull * lead + woff + incl - mybits;            // first grid bit of this thread
+            const uint64_t total_bits = (uint64_t)sym_bits + (uint64_t)lanes * tl + 1;
+            total_bytes = (uint32_t)((total_bits + 7) >> 3);
+            if ((8ull * lead + total_bits + 63) / 32 >= words_cap) rc = MICD_ERR_CAPACITY;
+            else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
+            if (rc == MICD_OK) {
+                // ---- 4. pack -------------------------------------------------------------------------
+                const uint32_t first_w = (uint32_t)(gstart >> 5);
+                const bool own_first = (gstart & 31) == 0;
+                uint32_t w = first_w;
+                uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 31);
+                uint32_t lead_val = 0; bool have_lead = false;
+                for (uint32_t idx = hi; idx > lo; idx--) {
+                    const uint32_t st = (uint32_t)stv[idx - 1] + size;
+                    const uint32_t nb = (st + tt_nb[src[idx - 1]]) >> 16;
+                    acc |= (uint64_t)(st & ((1u << nb) - 1u)) << filled;   // nb <= 16
+                    filled += nb;
+                    if (filled >= 32) {
+                        if (w > first_w || own_first) words[w] = (uint32_t)acc;
+                        else { lead_val = (uint32_t)acc; have_lead = true; }
+                        acc >>= 32; filled -= 32; w++;
+                    }
+                }
+                if (mybits > 0 && filled > 0) {
+                    if (w > first_w || own_first) words[w] = (uint32_t)acc;          // owner's partial word
+                    else { lead_val = (uint32_t)acc; have_lead = true; }
+                }
+                __threadfence_block();
+                __syncthreads();
+                if (have_lead && lead_val) atomicOr(&words[first_w], lead_val);
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0) {
+                    // final states, last lane first (fse2state.go:194-197), then the end mark
+                    uint64_t pos = 8ull * lead + sym_bits;
+                    const uint64_t end = pos + (uint64_t)lanes * tl + 1;
+                    for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
+                    for (int k = (int)lanes - 1; k >= 0; k--) {
+                        // end state of chain k = end state of its last non-empty segment
+                        const uint32_t mk = (n - (uint32_t)k + lanes - 1) / lanes;
+                        const uint32_t fs = s_E[cur][((mk - 1) / L) * lanes + (uint32_t)k];
+                        const uint64_t v = (uint64_t)(fs & (((uint64_t)1 << tl) - 1));  // addBits32NC(state, tl)
+                        const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
+                        words[wi] |= (uint32_t)(v << sh);
+                        if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
+                        pos += tl;
+                    }
+                    words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
+                }
+            }
+        }
+        __syncthreads();
+        if (rc == MICD_OK) {
+            if (tid == 0) {
+                if (lanes != 1) {
+                    u.blob[0] = 0xFF;
+                    u.blob[1] = lanes == 2 ? 0x02 : lanes == 4 ? 0x04 : 0x84;
+                    u.blob[2] = (uint8_t)n; u.blob[3] = (uint8_t)(n >> 8);
+                    u.blob[4] = (uint8_t)(n >> 16); u.blob[5] = (uint8_t)(n >> 24);
+                }
+                u.blob_len = ((lanes == 1) ? 0 : 6) + hdr_len + total_bytes;      // 1-state blob starts at blob + 6
+                u.nstates_used = (int32_t)lanes;
+                u.status = MICD_OK;
+            }
+            return;
+        }
+        if (lanes == 1 || rc == MICD_ERR_CAPACITY) { if (tid == 0) u.status = rc; return; }
+        __syncthreads();
     }
 }
 
@@ -566,6 +755,18 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
     if (t) t->mark("k_enc_tables");
     hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(256), 0, stream, d_units);
+    if (variant != 100) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            attr_done = true;
+        }
+        if (t) t->mark("k_enc_tans_wg");
+        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 13, stream, d_units, 5u, 13u);
+        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 14, stream, d_units, 14u, 14u);
+        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 15, stream, d_units, 15u, 15u);
+        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units, 16u, 16u);
+    }
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("end");
