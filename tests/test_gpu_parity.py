@@ -170,3 +170,80 @@ def test_corrupt_stream_is_an_error_not_a_hang(mic, mico, gpu_ready):
         mic.decompress_single_frame(bytes(bad), 256, 256)
     with pytest.raises(mic.MicError):
         mic.decompress_single_frame(blob[:40], 256, 256)
+
+
+def _piecewise_rows(synth, w, h, seed, alphabet, maxseg):
+    """Piecewise-constant rows with random segment lengths: dense in runs of every length around
+    the tokeniser's chunk size, plus isolated symbols between runs."""
+    r = synth.hash_u64(w * h * 2, seed)
+    vals = (r[: w * h] % np.uint64(alphabet)).astype(np.uint16)
+    lens = (r[w * h:] % np.uint64(maxseg)).astype(np.int64) + 1
+    out = np.empty(w * h, dtype=np.uint16)
+    pos = 0; k = 0
+    while pos < w * h:
+        n = int(lens[k]); out[pos:pos + n] = vals[k]; pos += n; k += 1
+    return out[: w * h].reshape(h, w)
+
+
+@pytest.mark.parametrize("maxv", [15, 31, 255, 1023])
+def test_tokeniser_fuzz_small_depths(mic, mico, synth, gpu_ready, maxv):
+    """Small depths make midCount tiny (7, 15, 127, 511): same-run and literal chunking
+    (rlecompressu16.go:57-67) fire constantly, including at the end of the stream."""
+    frames, want = [], []
+    for k in range(24):
+        w, h = 97 + 13 * k, 40 + (k % 5) * 9
+        f = _piecewise_rows(synth, w, h, 1000 + 31 * k + maxv, min(maxv, 6 + k % 7), 1 + (k * 7) % 40)
+        if k % 3 == 0:
+            f[:, : w // 3] = (np.arange(w // 3) * 7 % (maxv + 1)).astype(np.uint16)[None, :]   # long literal stretches
+        if k % 4 == 1:
+            f[-1, -(k % 6 + 1):] = (f[-1, -(k % 6 + 1):] + 1 + np.arange(k % 6 + 1)) % (maxv + 1)   # ragged stream end
+        frames.append(f)
+        want.append(mico.compress_single_frame(f, maxv, 2))
+    got = mic.compress_batch(frames, [maxv] * len(frames), 2)
+    n_ok = 0
+    for f, (st, blob, used), (rc, w_blob) in zip(frames, got, want):
+        assert st == rc, (st, rc, f.shape)
+        assert blob == w_blob, f.shape
+        if rc == 0:
+            n_ok += 1
+            assert np.array_equal(mic.decompress_single_frame(blob, f.shape[1], f.shape[0]), f)
+    assert n_ok >= 12
+
+
+@pytest.mark.parametrize("ns", [2, 4, 8])
+def test_tiny_and_ragged_frames(mic, mico, synth, gpu_ready, ns):
+    """Token counts around the lane count and segment boundaries of the parallel encoder; whatever
+    the oracle says (blob or error code, incl. the N -> ... -> 1 fallback) the GPU must say too."""
+    frames = []
+    for k, (w, h) in enumerate([(1, 1), (2, 1), (3, 1), (1, 7), (5, 2), (9, 1), (17, 3), (33, 2), (64, 1), (127, 3),
+                                (256, 4), (511, 2), (1023, 1), (1025, 3), (2049, 1), (4097, 2)]):
+        f = _piecewise_rows(synth, w, h, 77 + k, 5, 9)
+        frames.append(f)
+    got = mic.compress_batch(frames, [255] * len(frames), ns)
+    for f, (st, blob, used) in zip(frames, got):
+        rc, want = mico.compress_single_frame(f, 255, ns)
+        assert st == rc, (f.shape, st, rc)
+        assert blob == want, f.shape
+        if rc == 0:
+            assert np.array_equal(mic.decompress_single_frame(blob, f.shape[1], f.shape[0]), f)
+
+
+def test_sixteen_bit_depth_full_alphabet(mic, mico, synth, gpu_ready):
+    """maxValue 65535 -> delimiter 65535, 65536-symbol alphabet, tableLog 16 (the CT case)."""
+    img = synth.xr_like(cols=700, rows=300, depth=16, seed=9)
+    for ns in (2, 4, 8):
+        rc, want = mico.compress_single_frame(img, 65535, ns)
+        assert rc == 0
+        got = mic.compress_single_frame(img, 700, 300, 65535, ns)
+        assert got == want
+        assert np.array_equal(mic.decompress_single_frame(got, 700, 300), img)
+
+
+def test_strip_sized_unit_matches_oracle(mic, mico, synth, gpu_ready):
+    """One full XR strip (2577 x 256): the shape bench.py runs, bit-exact against the oracle."""
+    img = synth.xr_like(cols=2577, rows=256, depth=12, seed=3)
+    rc, want = mico.compress_single_frame(img, 4095, 2)
+    assert rc == 0
+    got = mic.compress_single_frame(img, 2577, 256, 4095, 2)
+    assert got == want
+    assert np.array_equal(mic.decompress_single_frame(got, 2577, 256), img)
