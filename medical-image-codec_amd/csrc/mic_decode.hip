@@ -173,24 +173,27 @@ __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
 
 
 // ==========================================================================================
-// Fast tANS decode: one wave per unit, decode table in LDS.
+// Fast tANS decode: one wave per unit, transition table in LDS.
 //
 // The N states of an N-state stream (fse2state.go:203-308, fse4state.go:195-353,
 // fse8state.go:230-380, rans8state.go:221-412) share ONE reverse bitstream, so the chain
 //   state_k -> table entry -> (nbBits, newState) -> bits at the running position -> state_k'
-// is serial per stream; a stream cannot be split (the format has no resynchronisation points,
-// DESIGN.md §tANS).  The kernel therefore minimises the latency of one chain step, measured
-// with tools/ubench_chain.hip (dependent ds_read = 70 cycles, every dependent VALU op ~10):
+// is serial per stream and a stream cannot be split (the format has no resynchronisation
+// points).  A lone wave issues one instruction every ~4-5 cycles whatever its
+// kind (tools/ubench_chain.hip: dependent ds_read 70 cycles, +30..45 cycles per added branch
+// or handful of scalar ops), so the loop is written for instruction COUNT:
 //   * all N look-ups of a group are issued together (one LDS round trip per N symbols);
-//   * the chain entry holds newState*4, nbBits and 32-nbBits ready-made: a state update is
-//     shift, shift-add (3 VALU ops for the second state of a pair), no clz / mask / multiply;
+//   * the transition entry holds newState, nbBits and 32-nbBits ready-made: a state update is
+//     shift + add (3 VALU ops for the second state of a pair);
 //   * every lane computes the same values (no cross-lane traffic on the chain); the bit window
-//     and its refill bookkeeping sit in SGPRs, the refill is branch-free;
+//     and its refill live in SGPRs, the refill is branch-free but for the buffer switch;
 //   * the stream is prefetched 64 dwords per load into a lane-distributed register buffer;
-//   * symbols are staged in LDS and leave as 256-byte coalesced stores.
-// LDS: chain[2^tl] u32 = newState*4 << 14 | (32-nbBits) << 8 | nbBits ; symt[2^tl] u16 ;
-//      stage[128] u16.   ZB = table has 0-bit entries (zeroBits, fsedecompressu16.go:214-216).
-// grid = units, block = 64, dynamic LDS = 6 << tl_hi + 256.
+//   * the loop stages STATES (16 bit), not symbols; every 128 symbols all 64 lanes translate
+//     state -> symbol through the L2-resident symbol table and store 256 bytes coalesced, one
+//     chunk behind the chain so the gather latency is hidden.
+// LDS: chain[2^tl] u32 = newState << 16 | (32-nbBits) << 8 | nbBits ; stage[2][64] u32.
+// ZB = table has 0-bit entries (zeroBits, fsedecompressu16.go:214-216).
+// grid = units, block = 64, dynamic LDS = 4 << tl_hi + 512.
 template <int N, bool ZB>
 __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
     extern __shared__ uint32_t s_mem[];
@@ -205,18 +208,17 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl
     const uint32_t lane = threadIdx.x;
     const uint32_t size = 1u << tl;
     uint32_t *chain = s_mem;
-    uint16_t *symt = (uint16_t *)(s_mem + size);
-    uint32_t *stage = s_mem + size + size / 2;                          // 64 dwords = 128 symbols
+    uint32_t *stage = s_mem + size;                                     // 2 x 64 dwords = 2 x 128 states
     {
-        const uint32_t *dt = u.tt_nb; const uint16_t *ds = u.tab_sym;
+        const uint32_t *dt = u.tt_nb;
         for (uint32_t p = lane; p < size; p += 64) {
-            uint32_t e = dt[p];                                         // newState | nbBits << 16
-            uint32_t nb = e >> 16;
+            const uint32_t e = dt[p];                                   // newState | nbBits << 16
+            const uint32_t nb = e >> 16;
             chain[p] = ((e & 0xFFFF) << 16) | ((32u - nb) << 8) | nb;
-            symt[p] = ds[p];
         }
     }
     __syncthreads();
+    const uint16_t *symg = u.tab_sym;                                   // state -> symbol, L2 resident
     const uint32_t count = u.count;
     uint16_t *out = u.tok;
     if (u.bits_off >= u.comp_len) { if (lane == 0) u.status = MICD_ERR_CORRUPT; return; }
@@ -232,110 +234,99 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl
     const uint32_t sb = (uint32_t)(addr & 3);
     const uint32_t *g = (const uint32_t *)(addr - sb);
     const uint64_t cur = total_bits + 8ull * sb;                        // unread bits are grid bits [8*sb, cur)
-    const int64_t top_dw = (int64_t)((cur - 1) >> 5);                   // dword holding the top unread bit
-    int64_t di = top_dw;
+    const int32_t top_dw = (int32_t)((cur - 1) >> 5);                   // dword holding the top unread bit (< 2^27)
+    int32_t di = top_dw;                                                // next dword to enter the window
     // lane-distributed stream buffer: buf_a = the 64 dwords of block di>>6, buf_b = the block below
-    auto load_blk = [&](int64_t b) -> uint32_t {
-        int64_t idx = b * 64 + (int64_t)lane;
+    auto load_blk = [&](int32_t b) -> uint32_t {
+        const int32_t idx = b * 64 + (int32_t)lane;
         return (b >= 0 && idx <= top_dw) ? g[idx] : 0u;
     };
     uint32_t buf_a = load_blk(di >> 6), buf_b = load_blk((di >> 6) - 1);
     uint64_t W = 0; uint32_t avail = 0;
-    uint64_t consumed = 0;
-    // take T (<= 32, uniform) bits off the window and top it up to >= 32 valid bits; branch-free
-    // except when the register buffer runs out (every 64 refills)
+    // take T (<= 32, uniform) bits off the window and top it up to >= 32 valid bits
     auto advance = [&](uint32_t T) {
-        W <<= T; avail -= T; consumed += T;
-        const uint32_t nd = __builtin_amdgcn_readlane(buf_a, (int)((uint32_t)di & 63u));
+        W <<= T; avail -= T;
+        const uint32_t nd = __builtin_amdgcn_readlane(buf_a, di & 63);
         const bool need = avail < 32;
         const uint64_t add = (uint64_t)nd << ((32u - avail) & 63u);
         W |= need ? add : 0ull;
         avail += need ? 32u : 0u;
-        if (need) {
-            if (((uint32_t)di & 63u) == 0u) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 2); }
-            di--;
-        }
+        const bool sw = need && ((di & 63) == 0);
+        di -= need ? 1 : 0;
+        if (sw) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 1); }     // every 64 refills
     };
     {   // prime the window: the top dword holds 1..32 valid bits
         const uint32_t top = (uint32_t)(cur - 32ull * (uint64_t)di);
-        W = (uint64_t)__builtin_amdgcn_readlane(buf_a, (int)((uint32_t)di & 63u)) << (64 - top);
+        W = (uint64_t)__builtin_amdgcn_readlane(buf_a, di & 63) << (64 - top);
         avail = top;
-        if (((uint32_t)di & 63u) == 0u) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 2); }
+        const bool sw = (di & 63) == 0;
         di--;
+        if (sw) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 1); }
         advance(0);
     }
-    uint32_t st[N];                                                     // states as LDS byte offsets (state*4)
+    uint32_t st[N];
     // initial states: state 0 first, tl bits each (fse2state.go:210-212)
 #pragma unroll
     for (int p = 0; p < N; p += 2) {
         const uint32_t hi = (uint32_t)(W >> 32);
-        st[p] = __builtin_amdgcn_ubfe(hi, 32u - tl, tl) << 2;
-        st[p + 1] = __builtin_amdgcn_ubfe(hi, 32u - 2u * tl, tl) << 2;
+        st[p] = __builtin_amdgcn_ubfe(hi, 32u - tl, tl);
+        st[p + 1] = __builtin_amdgcn_ubfe(hi, 32u - 2u * tl, tl);
         advance(2u * tl);
     }
-    const char *chain_b = (const char *)chain;
-    const char *symt_b = (const char *)symt;
-    const uint32_t groups = count / N;
-    uint32_t i = 0;
-#ifdef MIC_STAMP
-    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
-#endif
-    for (uint32_t gidx = 0; gidx < groups; gidx++, i += N) {
-        uint32_t e[N], sy[N];
+    // one group = N symbols, states 0..N-1 in order; bits are handed out pair by pair (<= 32 a pair)
+    auto group = [&](uint32_t *stage_w, uint32_t r) {                   // r = symbols wanted from this group (N, or fewer in the tail)
+        uint32_t e[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            e[k] = *(const uint32_t *)(chain_b + st[k]);
-            sy[k] = *(const uint16_t *)(symt_b + (st[k] >> 1));
-        }
+        for (int k = 0; k < N; k++) e[k] = chain[st[k]];
 #pragma unroll
         for (int p = 0; p < N; p += 2) {
             const uint32_t hi = (uint32_t)(W >> 32);
-            const uint32_t nb0 = e[p] & 0xFF, nb1 = e[p + 1] & 0xFF;
+            stage_w[p >> 1] = st[p] | (st[p + 1] << 16);
+            uint32_t nb0 = e[p] & 0xFF, nb1 = e[p + 1] & 0xFF;
+            if (r < (uint32_t)N) { nb0 = ((uint32_t)p < r) ? nb0 : 0u; nb1 = ((uint32_t)p + 1 < r) ? nb1 : 0u; }
             uint32_t b0, b1;
-            if (ZB) {
+            if (ZB || r < (uint32_t)N) {
                 b0 = __builtin_amdgcn_ubfe(hi, 32u - nb0, nb0);
                 b1 = __builtin_amdgcn_ubfe(hi, 32u - nb0 - nb1, nb1);
             } else {                                                    // nbBits >= 1: plain shifts
                 b0 = hi >> ((e[p] >> 8) & 0xFF);
                 b1 = (hi << nb0) >> ((e[p + 1] >> 8) & 0xFF);
             }
-            st[p] = (b0 << 2) + ((e[p] >> 16) << 2);
-            st[p + 1] = (b1 << 2) + ((e[p + 1] >> 16) << 2);
-            stage[((i & 127u) >> 1) + (p >> 1)] = sy[p] | (sy[p + 1] << 16);
+            st[p] = b0 + (e[p] >> 16);
+            st[p + 1] = b1 + (e[p + 1] >> 16);
             advance(__builtin_amdgcn_readfirstlane(nb0 + nb1));
         }
-        if (((i + N) & 127u) == 0) {                                    // 128 symbols staged: one 256-B store
-            ((uint32_t *)out)[((i + N - 128u) >> 1) + lane] = stage[lane];
-        }
+    };
+    constexpr uint32_t G = 128 / N;                                     // groups per 128-symbol chunk
+    const uint32_t chunks = count / 128;
+    uint32_t pend = 0; bool have_pend = false;                          // symbols gathered for the previous chunk
+    uint32_t obase = 0;                                                 // dword index of the pending chunk in out
+    for (uint32_t ch = 0; ch < chunks; ch++) {
+        uint32_t *sw = stage + (ch & 1) * 64;
+#pragma unroll 4
+        for (uint32_t gi = 0; gi < G; gi++) group(sw + gi * (N / 2), N);
+        // this chunk's 128 states are staged: write out the previous chunk, gather this one
+        if (have_pend) ((uint32_t *)out)[obase + lane] = pend;
+        const uint32_t s2 = sw[lane];
+        pend = (uint32_t)symg[s2 & 0xFFFF] | ((uint32_t)symg[s2 >> 16] << 16);
+        have_pend = true; obase = ch * 64;
     }
-#ifdef MIC_STAMP
-    if (lane == 0) { u.max_count = (uint32_t)(__builtin_amdgcn_s_memtime() - t_loop0); u.hdr_len = groups; }
-#endif
-    // tail: count % N symbols, states 0 .. r-1 in order (fse2state.go:293-305)
-    const uint32_t r = count - i;
-    if (r) {
-        uint32_t e[N], sy[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            e[k] = *(const uint32_t *)(chain_b + st[k]);
-            sy[k] = *(const uint16_t *)(symt_b + (st[k] >> 1));
-        }
-#pragma unroll
-        for (int p = 0; p < N; p += 2) {
-            const uint32_t nb0 = ((uint32_t)p < r) ? (e[p] & 0xFF) : 0u;
-            const uint32_t nb1 = ((uint32_t)p + 1 < r) ? (e[p + 1] & 0xFF) : 0u;
-            stage[((i & 127u) >> 1) + (p >> 1)] = sy[p] | (sy[p + 1] << 16);
-            advance(__builtin_amdgcn_readfirstlane(nb0 + nb1));
-        }
-    }
-    // flush the partially filled stage (symbols [i & ~127, count))
+    if (have_pend) ((uint32_t *)out)[obase + lane] = pend;
+    // tail: count % 128 symbols (fse2state.go:293-305 for the last partial group)
     {
-        const uint32_t base = i & ~127u;
-        const uint16_t *st16 = (const uint16_t *)stage;
-        for (uint32_t k = lane; base + k < count && k < 128; k += 64) out[base + k] = st16[k];
+        const uint32_t done = chunks * 128;
+        const uint32_t rem = count - done;
+        uint32_t *sw = stage + (chunks & 1) * 64;
+        uint32_t k = 0;
+        for (; k + N <= rem; k += N) group(sw + (k / 2), N);
+        if (k < rem) group(sw + (k / 2), rem - k);
+        const uint16_t *st16 = (const uint16_t *)sw;
+        for (uint32_t j = lane; j < rem; j += 64) out[done + j] = symg[st16[j]];
     }
     if (lane == 0) {
-        if (consumed > total_bits) u.status = MICD_ERR_CORRUPT;         // bitreader.go:113-120
+        // bits taken = total - (bits still in the window + bits in dwords not yet fetched)
+        const int64_t unread = (int64_t)avail + 32ll * ((int64_t)di + 1) - 8ll * sb;
+        if (unread < 0) u.status = MICD_ERR_CORRUPT;                    // bitreader.go:113-120
         else u.ntok = count;
     }
 }
@@ -347,8 +338,9 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (6u << 13) + 256, stream, d_units, 5u, 13u);
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (6u << 14) + 256, stream, d_units, 14u, 14u);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 13) + 512, stream, d_units, 5u, 13u);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 14) + 512, stream, d_units, 14u, 14u);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 15) + 512, stream, d_units, 15u, 15u);
 }
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
