@@ -13,36 +13,76 @@
 #include "mic_fse_tables.h"
 #include "mic_launch.h"
 
-// grid = units, block = 64; lane 0 parses (the NCount header is a serial bit-parse).
-__global__ void __launch_bounds__(64) k_dec_tables(MicUnit *units) {
+// grid = units, block = 256.  The NCount header is a serial bit-parse and the table build has
+// data-dependent loops (mic_fse_tables.h), so one lane runs them -- on LDS copies: the first
+// 16 KiB of the blob (the header is at most symbolLen*tableLog/8+3 bytes), norm[], the symbol
+// spread and the per-symbol counters.  The finished table goes to HBM as stores.
+#define DT_STAGE_BYTES 16384
+#define DT_SMALL_SYMS 8192
+#define DT_SMALL_TL 13
+__global__ void __launch_bounds__(256) k_dec_tables(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    u.status = MICD_OK; u.ntok = 0;
-    if (u.w <= 0 || u.h <= 0 || !u.comp_in) { u.status = MICD_ERR_ARGS; return; }
-    const uint8_t *b = u.comp_in;
-    uint32_t len = u.comp_len;
-    // FSEDecompressU16Auto, fse2state.go:102-116
-    uint32_t flavour = 1;
-    if (len >= 2 && b[0] == 0xFF) {
-        if (b[1] == 0x84) flavour = 8;
-        else if (b[1] == 0x08) flavour = 108;
-        else if (b[1] == 0x04) flavour = 4;
-        else if (b[1] == 0x02) flavour = 2;
+    __shared__ uint8_t s_in[DT_STAGE_BYTES];
+    __shared__ int32_t s_norm[DT_SMALL_SYMS];
+    __shared__ int32_t s_next[DT_SMALL_SYMS];
+    __shared__ uint16_t s_tabsym[1 << DT_SMALL_TL];
+    __shared__ uint32_t s_flag[2];
+    const uint32_t len = u.comp_len;
+    if (u.comp_in) for (uint32_t i = threadIdx.x; i < len && i < DT_STAGE_BYTES; i += blockDim.x) s_in[i] = u.comp_in[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_flag[0] = 0;
+        u.status = MICD_OK; u.ntok = 0;
+        do {
+            if (u.w <= 0 || u.h <= 0 || !u.comp_in) { u.status = MICD_ERR_ARGS; break; }
+            const uint8_t *b = (len <= DT_STAGE_BYTES) ? s_in : u.comp_in;   // short blobs parse entirely from LDS
+            // FSEDecompressU16Auto, fse2state.go:102-116
+            uint32_t flavour = 1;
+            if (len >= 2 && s_in[0] == 0xFF) {
+                if (s_in[1] == 0x84) flavour = 8;
+                else if (s_in[1] == 0x08) flavour = 108;
+                else if (s_in[1] == 0x04) flavour = 4;
+                else if (s_in[1] == 0x02) flavour = 2;
+            }
+            uint32_t count = 0, off = 0;
+            if (flavour != 1) {
+                if (len < 6) { u.status = MICD_ERR_CORRUPT; break; }
+                count = (uint32_t)s_in[2] | ((uint32_t)s_in[3] << 8) | ((uint32_t)s_in[4] << 16) | ((uint32_t)s_in[5] << 24);
+                off = 6;
+                if (count > u.tok_cap) { u.status = MICD_ERR_CORRUPT; break; }
+            }
+            u.flavour = flavour; u.count = count;
+            // Parse from the staged bytes when the whole header is certain to be inside them
+            // (it ends before the stage does unless the parser runs to the stage's last 8 bytes).
+            uint32_t used = 0, symbol_len = 0, tl = 0;
+            int rc;
+            bool lds_norm = false;
+            if (len > DT_STAGE_BYTES) {
+                rc = mic_read_ncount(s_in + off, DT_STAGE_BYTES - off, s_norm, &symbol_len, &tl, &used, DT_SMALL_SYMS);
+                if (rc == MICD_OK && used + 8 < DT_STAGE_BYTES - off && symbol_len <= DT_SMALL_SYMS) lds_norm = true;
+                else rc = mic_read_ncount(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536);
+            } else {
+                rc = mic_read_ncount(b + off, len - off, s_norm, &symbol_len, &tl, &used, DT_SMALL_SYMS);
+                if (rc == MICD_OK) lds_norm = true;
+                else if (rc == MICD_ERR_UNSUPPORTED) rc = mic_read_ncount(b + off, len - off, u.norm, &symbol_len, &tl, &used, 65536);
+            }
+            if (rc) { u.status = rc; break; }
+            u.symbol_len = symbol_len; u.table_log = tl;
+            u.bits_off = off + used;
+            MicUnit v = u;
+            const bool small = lds_norm && tl <= DT_SMALL_TL;
+            if (lds_norm) v.norm = s_norm;
+            if (small) { v.tt_find = s_next; v.tab_sym = s_tabsym; }
+            rc = (flavour == 108) ? mic_build_rans_dtable(v) : mic_build_dtable(v);
+            if (rc) { u.status = rc; break; }
+            u.zero_bits = v.zero_bits;
+            if (small) s_flag[0] = 1u << tl;
+        } while (0);
     }
-    uint32_t count = 0, off = 0;
-    if (flavour != 1) {
-        if (len < 6) { u.status = MICD_ERR_CORRUPT; return; }
-        count = (uint32_t)b[2] | ((uint32_t)b[3] << 8) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 24);
-        off = 6;
-        if (count > u.tok_cap) { u.status = MICD_ERR_CORRUPT; return; }
-    }
-    u.flavour = flavour; u.count = count;
-    uint32_t used = 0;
-    int rc = mic_read_ncount(b + off, len - off, u.norm, &u.symbol_len, &u.table_log, &used);
-    if (rc) { u.status = rc; return; }
-    u.bits_off = off + used;
-    rc = (flavour == 108) ? mic_build_rans_dtable(u) : mic_build_dtable(u);
-    if (rc) { u.status = rc; return; }
+    __syncthreads();
+    // symbol-of-state table was built in LDS: copy it out
+    const uint32_t nsz = s_flag[0];
+    for (uint32_t i = threadIdx.x; i < nsz; i += blockDim.x) u.tab_sym[i] = s_tabsym[i];
 }
 
 // Reverse bit reader (bitreader.go): the highest set bit of the last byte is the end mark;
@@ -345,7 +385,7 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream) {
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
     if (t) t->mark("k_dec_tables");
-    hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(64), 0, stream, d_units);
+    hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(256), 0, stream, d_units);
     if (variant != 100) {
         if (t) t->mark("k_dec_tans_lds");
         launch_tans_lds<2, false>(d_units, n, stream);

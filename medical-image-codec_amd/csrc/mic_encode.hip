@@ -403,14 +403,25 @@ __global__ void __launch_bounds__(256) k_enc_hist(MicUnit *units) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Gates + tables.  grid = units, block = 256 (parallel max / symbolLen reduction, then lane 0).
+// Gates + tables.  grid = units, block = 256.  The table maths is the reference's serial code
+// (mic_fse_tables.h); what this kernel adds is locality: for the common case (alphabet <= 8192
+// symbols, tableLog <= 13) the histogram, norm[], cumul[] and tableSymbol[] working arrays live
+// in LDS, so the single lane that runs the data-dependent loops pays ~70-cycle LDS latencies
+// instead of HBM/L2 round trips; stateTable / symbolTT go straight to HBM as stores.
+#define ET_SMALL_SYMS 8192
+#define ET_SMALL_TL 13
 __global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK) return;
     __shared__ uint32_t s_max[256], s_len[256];
+    __shared__ uint32_t s_hist[ET_SMALL_SYMS];
+    __shared__ int32_t s_norm[ET_SMALL_SYMS];
+    __shared__ int32_t s_cumul[ET_SMALL_SYMS + 8];
+    __shared__ uint16_t s_tabsym[1 << ET_SMALL_TL];
     uint32_t m = 0, sl = 0;
     for (uint32_t i = threadIdx.x; i <= MIC_MAXSYM; i += blockDim.x) {
         uint32_t c = u.hist[i];
+        if (i < ET_SMALL_SYMS) s_hist[i] = c;
         if (c) { if (c > m) m = c; if (i + 1 > sl) sl = i + 1; }
     }
     s_max[threadIdx.x] = m; s_len[threadIdx.x] = sl;
@@ -431,14 +442,20 @@ __global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
     if (u.max_count == n) { u.status = MICD_ERR_USE_RLE; return; }
     if (u.max_count == 1 || u.max_count < (n >> 15)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
     u.table_log = mic_optimal_table_log(n, u.symbol_len);
-    int rc = mic_normalize_count(u.hist, u.norm, u.symbol_len, n, u.table_log);
+    const bool small = u.symbol_len <= ET_SMALL_SYMS && u.table_log <= ET_SMALL_TL;
+    MicUnit v = u;                                  // working copy whose scratch arrays may point into LDS
+    const uint32_t *hist = u.hist;
+    if (small) { hist = s_hist; v.norm = s_norm; v.cumul = s_cumul; v.tab_sym = s_tabsym; }
+    int rc = mic_normalize_count(hist, v.norm, v.symbol_len, n, v.table_log);
     if (rc) { u.status = rc; return; }
     if (u.blob_cap < 6 + 8) { u.status = MICD_ERR_CAPACITY; return; }
-    rc = mic_write_ncount(u.norm, u.symbol_len, u.table_log, u.blob + 6, u.blob_cap - 6, &u.hdr_len);
+    rc = mic_write_ncount(v.norm, v.symbol_len, v.table_log, u.blob + 6, u.blob_cap - 6, &v.hdr_len);
     if (rc) { u.status = rc; return; }
+    u.hdr_len = v.hdr_len;
     for (int k = 0; k < 8; k++) u.blob[6 + u.hdr_len + k] = 0;   // k_enc_tans_wg ORs into the first stream word
-    rc = mic_build_ctable(u);
+    rc = mic_build_ctable(v);
     if (rc) { u.status = rc; return; }
+    u.zero_bits = v.zero_bits;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -542,30 +559,228 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 // LDS: stateTable as u16 (state - 2^tl).  grid = units, block = 1024, dynamic LDS = 2 << tl.
 #define TE_THREADS 1024
 #define TE_WAVES 16
+#define TE_BLK 32                 // tokens per 64-byte block
+
+// One block of 32 tokens / 32 recorded states as four 16-byte vectors.
+struct TeBlk { uint4 v[4]; };
+__device__ __forceinline__ TeBlk te_load(const uint16_t *p) {
+    TeBlk b; const uint4 *q = (const uint4 *)p;
+    b.v[0] = q[0]; b.v[1] = q[1]; b.v[2] = q[2]; b.v[3] = q[3];
+    return b;
+}
+__device__ __forceinline__ void te_store(uint16_t *p, const TeBlk &b) {
+    uint4 *q = (uint4 *)p; q[0] = b.v[0]; q[1] = b.v[1]; q[2] = b.v[2]; q[3] = b.v[3];
+}
+__device__ __forceinline__ uint32_t te_get(const TeBlk &b, int j) {   // j compile-time after unrolling
+    const uint4 &v = b.v[j >> 3];
+    const uint32_t w = ((j >> 1) & 3) == 0 ? v.x : ((j >> 1) & 3) == 1 ? v.y : ((j >> 1) & 3) == 2 ? v.z : v.w;
+    return (j & 1) ? (w >> 16) : (w & 0xFFFF);
+}
+__device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
+    uint4 &v = b.v[j >> 3];
+    uint32_t &w = ((j >> 1) & 3) == 0 ? v.x : ((j >> 1) & 3) == 1 ? v.y : ((j >> 1) & 3) == 2 ? v.z : v.w;
+    w = (j & 1) ? ((w & 0xFFFFu) | (x << 16)) : ((w & 0xFFFF0000u) | (x & 0xFFFF));
+}
+
+// Thread t (t = 0 encodes first) owns the 32-token blocks [b_lo, b_hi); all N chains of those
+// tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
+template <int N>
+__device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
+    const uint16_t *src = u.tok;
+    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
+    uint16_t *stv = u.sym;
+    const uint32_t hdr_len = u.hdr_len;
+    uint8_t *bits_base = u.blob + 6 + hdr_len;
+    const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 3);
+    uint32_t *words = (uint32_t *)(bits_base - lead);
+    const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
+    const uint32_t nblk = (n + TE_BLK - 1) / TE_BLK;
+    const uint32_t per = (nblk + TE_THREADS - 1) / TE_THREADS;
+    const uint32_t b_hi = (tid * per < nblk) ? nblk - tid * per : 0;
+    const uint32_t b_lo = (b_hi > per) ? b_hi - per : 0;
+    // ---- 1. speculative walk from the guessed state 2^tl --------------------------------------
+    uint32_t st[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) st[k] = size;
+    for (uint32_t b = b_hi; b > b_lo; b--) {
+        const uint32_t base = (b - 1) * TE_BLK;
+        const TeBlk tk = te_load(src + base);
+        TeBlk rec;                                   // every half-word is written below; start defined (no poison)
+        rec.v[0] = rec.v[1] = rec.v[2] = rec.v[3] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = TE_BLK - 1; j >= 0; j--) {
+            if (base + (uint32_t)j < n) {
+                const uint32_t sy = te_get(tk, j);
+                const int k = j & (N - 1);
+                te_set(rec, j, st[k] - size);
+                const uint32_t nb = (st[k] + tt_nb[sy]) >> 16;
+                st[k] = size + s_stab[(int32_t)(st[k] >> nb) + tt_find[sy]];
+            } else te_set(rec, j, 0);
+        }
+        te_store(stv + base, rec);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
+    uint32_t assumed[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) assumed[k] = size;
+    // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
+    for (uint32_t round = 0; round < TE_THREADS; round++) {
+        __syncthreads();
+        int changed = 0;
+        uint32_t e_out[N], st2[N]; bool act[N]; bool any = false;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            e_out[k] = (uint32_t)s_E[tid][k] + size;
+            const uint32_t e_prev = (tid > 0) ? (uint32_t)s_E[tid - 1][k] + size : size;
+            act[k] = (tid > 0) && (e_prev != assumed[k]) ;
+            if (act[k]) { assumed[k] = e_prev; any = true; }
+            st2[k] = e_prev;
+        }
+        if (any) {
+            if (b_hi == b_lo) {            // no tokens: hand the states on (never asks for another round)
+#pragma unroll
+                for (int k = 0; k < N; k++) if (act[k]) e_out[k] = st2[k];
+            } else {
+                for (uint32_t b = b_hi; b > b_lo && any; b--) {
+                    const uint32_t base = (b - 1) * TE_BLK;
+                    const TeBlk tk = te_load(src + base);
+                    TeBlk rec = te_load(stv + base);
+#pragma unroll
+                    for (int j = TE_BLK - 1; j >= 0; j--) {
+                        const int k = j & (N - 1);
+                        if (base + (uint32_t)j < n && act[k]) {
+                            if (te_get(rec, j) + size == st2[k]) act[k] = false;       // merged with the recorded walk
+                            else {
+                                const uint32_t sy = te_get(tk, j);
+                                te_set(rec, j, st2[k] - size);
+                                const uint32_t nb = (st2[k] + tt_nb[sy]) >> 16;
+                                st2[k] = size + s_stab[(int32_t)(st2[k] >> nb) + tt_find[sy]];
+                            }
+                        }
+                    }
+                    te_store(stv + base, rec);
+                    any = false;
+#pragma unroll
+                    for (int k = 0; k < N; k++) any = any || act[k];
+                }
+#pragma unroll
+                for (int k = 0; k < N; k++) if (act[k] && st2[k] != e_out[k]) { e_out[k] = st2[k]; changed = 1; }
+            }
+        }
+        __syncthreads();                                   // every thread has read its predecessor's states
+#pragma unroll
+        for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(e_out[k] - size);
+        if (!__syncthreads_or(changed)) break;
+    }
+    __syncthreads();
+    // empty tail threads may not have been reached by a round: propagate the final states down
+    // (thread T-1 must hold the end states of every chain for the trailer)
+    if (tid == 0) {
+        // last thread that owns tokens
+        uint32_t last = (nblk + per - 1) / per; if (last > 0) last--;
+        for (int k = 0; k < N; k++) s_E[TE_THREADS - 1][k] = s_E[last][k];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 3. bit offsets ---------------------------------------------------------------------------
+    uint32_t mybits = 0;
+    for (uint32_t b = b_hi; b > b_lo; b--) {
+        const uint32_t base = (b - 1) * TE_BLK;
+        const TeBlk tk = te_load(src + base);
+        const TeBlk rec = te_load(stv + base);
+#pragma unroll
+        for (int j = TE_BLK - 1; j >= 0; j--)
+            if (base + (uint32_t)j < n) mybits += (te_get(rec, j) + size + tt_nb[te_get(tk, j)]) >> 16;
+    }
+    const uint32_t incl = tk_wave_incl_add(mybits, lane);
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, sym_bits = 0;
+#pragma unroll
+    for (int wv = 0; wv < TE_WAVES; wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
+    const uint64_t gstart = 8ull * lead + woff + incl - mybits;            // first grid bit of this thread
+    const uint64_t total_bits = (uint64_t)sym_bits + (uint64_t)N * tl + 1;
+    const uint32_t total_bytes = (uint32_t)((total_bits + 7) >> 3);
+    // the verdict goes through LDS so that every thread (and the caller) sees one value
+    if (tid == 0) {
+        int rc0 = MICD_OK;
+        if ((8ull * lead + total_bits + 63) / 32 >= words_cap) rc0 = MICD_ERR_CAPACITY;
+        else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc0 = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
+        s_scan[TE_WAVES] = (uint32_t)rc0; s_scan[TE_WAVES + 1] = total_bytes;
+    }
+    __syncthreads();
+    const int rc = (int)s_scan[TE_WAVES];
+    total_bytes_out = s_scan[TE_WAVES + 1];
+    rc_out = rc;
+    if (rc != MICD_OK) return;
+    // ---- 4. pack -------------------------------------------------------------------------------------
+    const uint32_t first_w = (uint32_t)(gstart >> 5);
+    const bool own_first = (gstart & 31) == 0;
+    uint32_t w = first_w;
+    uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 31);
+    uint32_t lead_val = 0; bool have_lead = false;
+    for (uint32_t b = b_hi; b > b_lo; b--) {
+        const uint32_t base = (b - 1) * TE_BLK;
+        const TeBlk tk = te_load(src + base);
+        const TeBlk rec = te_load(stv + base);
+#pragma unroll
+        for (int j = TE_BLK - 1; j >= 0; j--) {
+            if (base + (uint32_t)j < n) {
+                const uint32_t stt = te_get(rec, j) + size;
+                const uint32_t nb = (stt + tt_nb[te_get(tk, j)]) >> 16;
+                acc |= (uint64_t)(stt & ((1u << nb) - 1u)) << filled;   // nb <= 16
+                filled += nb;
+                if (filled >= 32) {
+                    if (w > first_w || own_first) words[w] = (uint32_t)acc;
+                    else { lead_val = (uint32_t)acc; have_lead = true; }
+                    acc >>= 32; filled -= 32; w++;
+                }
+            }
+        }
+    }
+    if (mybits > 0 && filled > 0) {
+        if (w > first_w || own_first) words[w] = (uint32_t)acc;          // owner's partial word
+        else { lead_val = (uint32_t)acc; have_lead = true; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (have_lead && lead_val) atomicOr(&words[first_w], lead_val);
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        // final states, last lane first (fse2state.go:194-197), then the end mark
+        uint64_t pos = 8ull * lead + sym_bits;
+        const uint64_t end = pos + (uint64_t)N * tl + 1;
+        for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            const uint64_t v = (uint64_t)((uint32_t)s_E[TE_THREADS - 1][k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
+            const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
+            words[wi] |= (uint32_t)(v << sh);
+            if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
+            pos += tl;
+        }
+        words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
+    }
+}
 
 __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
     extern __shared__ uint16_t s_stab[];
-    __shared__ uint32_t s_E[2][TE_THREADS];
-    __shared__ uint32_t s_scan[TE_WAVES];
+    __shared__ uint16_t s_E[TE_THREADS][8];
+    __shared__ uint32_t s_scan[TE_WAVES + 2];
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.nstates_used != 0) return;
     const uint32_t tl = u.table_log;
     if (tl < tl_lo || tl > tl_hi) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
-    const uint16_t *src = u.tok;
-    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
-    uint16_t *stv = u.sym;                                   // state - 2^tl in front of every token
-    if (u.sym_cap < n) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
+    if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
     for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
-    uint8_t *bits_base = u.blob + 6 + hdr_len;               // the bitstream sits right behind the NCount header
-    const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 3);
-    uint32_t *words = (uint32_t *)(bits_base - lead);        // aligned word grid; grid bit 8*lead = stream bit 0
-    const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
-
     for (uint32_t lanes = u.nstates; lanes >= 1; lanes >>= 1) {
         // length gates: fse8state.go:32, fse4state.go:25, fse2state.go:23, fsecompressu16.go:20
         int rc = MICD_OK;
@@ -573,118 +788,10 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint
         else if (n <= 2 && lanes <= 2) rc = MICD_ERR_INTERNAL;                   // "src too small"
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
-            // ---- 1. speculative walks --------------------------------------------------------
-            const uint32_t tpc = TE_THREADS / lanes;           // threads per chain
-            const uint32_t ch = tid % lanes, sg = tid / lanes; // chain, segment
-            const uint32_t m = (n > ch) ? (n - ch + lanes - 1) / lanes : 0;      // symbols on this chain
-            const uint32_t L = ((n + lanes - 1) / lanes + tpc - 1) / tpc;        // segment length (uniform)
-            const uint32_t r0 = min(m, sg * L), r1 = min(m, r0 + L);
-            // chain position r (0 = encoded first) <-> token index ch + lanes*(m-1-r)
-            uint32_t state = size;
-            for (uint32_t r = r0; r < r1; r++) {
-                const uint32_t idx = ch + lanes * (m - 1 - r);
-                const uint32_t sy = src[idx];
-                stv[idx] = (uint16_t)(state - size);
-                const uint32_t nb = (state + tt_nb[sy]) >> 16;
-                state = size + s_stab[(int32_t)(state >> nb) + tt_find[sy]];
-            }
-            s_E[0][tid] = state;
-            uint32_t assumed = size;                            // start state the recorded walk assumed
-            // ---- 2. fix-up rounds ---------------------------------------------------------------
-            uint32_t cur = 0;
-            for (uint32_t round = 0; round < TE_THREADS; round++) {
-                __syncthreads();
-                int changed = 0;
-                uint32_t e_out = s_E[cur][tid];
-                if (sg > 0) {
-                    const uint32_t e_prev = s_E[cur][tid - lanes];
-                    if (e_prev != assumed) {
-                        assumed = e_prev;
-                        uint32_t st2 = e_prev; uint32_t r = r0;
-                        for (; r < r1; r++) {
-                            const uint32_t idx = ch + lanes * (m - 1 - r);
-                            if ((uint32_t)stv[idx] + size == st2) break;          // merged with the recorded walk
-                            const uint32_t sy = src[idx];
-                            stv[idx] = (uint16_t)(st2 - size);
-                            const uint32_t nb = (st2 + tt_nb[sy]) >> 16;
-                            st2 = size + s_stab[(int32_t)(st2 >> nb) + tt_find[sy]];
-                        }
-                        // an empty segment (r0 == r1) just hands the state on; it never asks for a round
-                        if (r == r1 && st2 != e_out) { e_out = st2; changed = (r1 > r0) ? 1 : 0; }
-                    }
-                }
-                s_E[cur ^ 1][tid] = e_out;
-                cur ^= 1;
-                if (!__syncthreads_or(changed)) break;
-            }
-            __syncthreads();
-            __threadfence_block();
-            // final state of every chain = end state of its last segment
-            // ---- 3. bit offsets ---------------------------------------------------------------------
-            const uint32_t R = (n + TE_THREADS - 1) / TE_THREADS;
-            const uint32_t hi = (tid * R < n) ? n - tid * R : 0;       // tokens [lo, hi), emitted from hi-1 down
-            const uint32_t lo = (hi > R) ? hi - R : 0;
-            uint32_t mybits = 0;
-            for (uint32_t idx = hi; idx > lo; idx--) {
-                const uint32_t st = (uint32_t)stv[idx - 1] + size;
-                mybits += (st + tt_nb[src[idx - 1]]) >> 16;
-            }
-            uint32_t incl = tk_wave_incl_add(mybits, lane);
-            if (lane == 63) s_scan[wave] = incl;
-            __syncthreads();
-            uint32_t woff = 0, sym_bits = 0;
-#pragma unroll
-            for (int wv = 0; wv < TE_WAVES; wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
-            const uint64_t gstart = 8ull * lead + woff + incl - mybits;            // first grid bit of this thread
-            const uint64_t total_bits = (uint64_t)sym_bits + (uint64_t)lanes * tl + 1;
-            total_bytes = (uint32_t)((total_bits + 7) >> 3);
-            if ((8ull * lead + total_bits + 63) / 32 >= words_cap) rc = MICD_ERR_CAPACITY;
-            else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
-            if (rc == MICD_OK) {
-                // ---- 4. pack -------------------------------------------------------------------------
-                const uint32_t first_w = (uint32_t)(gstart >> 5);
-                const bool own_first = (gstart & 31) == 0;
-                uint32_t w = first_w;
-                uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 31);
-                uint32_t lead_val = 0; bool have_lead = false;
-                for (uint32_t idx = hi; idx > lo; idx--) {
-                    const uint32_t st = (uint32_t)stv[idx - 1] + size;
-                    const uint32_t nb = (st + tt_nb[src[idx - 1]]) >> 16;
-                    acc |= (uint64_t)(st & ((1u << nb) - 1u)) << filled;   // nb <= 16
-                    filled += nb;
-                    if (filled >= 32) {
-                        if (w > first_w || own_first) words[w] = (uint32_t)acc;
-                        else { lead_val = (uint32_t)acc; have_lead = true; }
-                        acc >>= 32; filled -= 32; w++;
-                    }
-                }
-                if (mybits > 0 && filled > 0) {
-                    if (w > first_w || own_first) words[w] = (uint32_t)acc;          // owner's partial word
-                    else { lead_val = (uint32_t)acc; have_lead = true; }
-                }
-                __threadfence_block();
-                __syncthreads();
-                if (have_lead && lead_val) atomicOr(&words[first_w], lead_val);
-                __threadfence_block();
-                __syncthreads();
-                if (tid == 0) {
-                    // final states, last lane first (fse2state.go:194-197), then the end mark
-                    uint64_t pos = 8ull * lead + sym_bits;
-                    const uint64_t end = pos + (uint64_t)lanes * tl + 1;
-                    for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
-                    for (int k = (int)lanes - 1; k >= 0; k--) {
-                        // end state of chain k = end state of its last non-empty segment
-                        const uint32_t mk = (n - (uint32_t)k + lanes - 1) / lanes;
-                        const uint32_t fs = s_E[cur][((mk - 1) / L) * lanes + (uint32_t)k];
-                        const uint64_t v = (uint64_t)(fs & (((uint64_t)1 << tl) - 1));  // addBits32NC(state, tl)
-                        const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
-                        words[wi] |= (uint32_t)(v << sh);
-                        if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
-                        pos += tl;
-                    }
-                    words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
-                }
-            }
+            if (lanes == 8) te_encode<8>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else if (lanes == 4) te_encode<4>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else if (lanes == 2) te_encode<2>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else te_encode<1>(u, s_stab, s_E, s_scan, rc, total_bytes);
         }
         __syncthreads();
         if (rc == MICD_OK) {
@@ -701,6 +808,7 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint
             }
             return;
         }
+        if (tid == 0) { u.count = (uint32_t)rc; u.bits_off = total_bytes; u.flavour = lanes; }   // probe: why the attempt failed
         if (lanes == 1 || rc == MICD_ERR_CAPACITY) { if (tid == 0) u.status = rc; return; }
         __syncthreads();
     }
@@ -758,7 +866,7 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     if (variant != 100) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr_done = true;
         }
         if (t) t->mark("k_enc_tans_wg");
