@@ -384,8 +384,13 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream) {
 }
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
-    if (t) t->mark("k_dec_tables");
-    hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(256), 0, stream, d_units);
+    if (variant == 100) {
+        if (t) t->mark("k_dec_tables");
+        hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(256), 0, stream, d_units);
+    } else {
+        if (t) t->mark("k_dec_tables_wg");
+        mic_launch_dec_tables(d_units, n, stream);
+    }
     if (variant != 100) {
         if (t) t->mark("k_dec_tans_lds");
         launch_tans_lds<2, false>(d_units, n, stream);

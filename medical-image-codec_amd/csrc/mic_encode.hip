@@ -861,8 +861,13 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     }
     if (t) t->mark("k_enc_hist");
     hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
-    if (t) t->mark("k_enc_tables");
-    hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(256), 0, stream, d_units);
+    if (variant == 100) {
+        if (t) t->mark("k_enc_tables");
+        hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(256), 0, stream, d_units);
+    } else {
+        if (t) t->mark("k_enc_tables_wg");
+        mic_launch_enc_tables(d_units, n, stream);
+    }
     if (variant != 100) {
         static bool attr_done = false;
         if (!attr_done) {

@@ -119,7 +119,8 @@ __device__ inline int mic_normalize_count(const uint32_t *count, int32_t *norm, 
 
 // fsecompressu16.go:191-289 (writeCount); single lane.  Writes at out[0..), returns the
 // header length through *hdr_len.  cap must cover ((symbol_len*tl)>>3)+3+2 bytes.
-__device__ inline int mic_write_ncount(const int32_t *norm, uint32_t symbol_len, uint32_t tl,
+template <typename NormT>
+__device__ inline int mic_write_ncount(const NormT *norm, uint32_t symbol_len, uint32_t tl,
                                        uint8_t *out, uint32_t cap, uint32_t *hdr_len) {
     int table_size = 1 << tl;
     bool previous0 = false;
@@ -160,7 +161,7 @@ __device__ inline int mic_write_ncount(const int32_t *norm, uint32_t symbol_len,
                 bit_count -= 16;
             }
         }
-        int32_t count = norm[charnum];
+        int32_t count = (int32_t)norm[charnum];
         charnum++;
         int32_t max = (2 * threshold - 1) - remaining;
         if (count < 0) remaining += count; else remaining -= count;
@@ -259,7 +260,8 @@ __device__ inline uint32_t mic_rd_u32(const uint8_t *b, uint32_t len, int64_t of
 // fsedecompressu16.go:48-167 (readNCount); single lane.  b/len = stream after the prefix.
 // norm_cap: entries available in norm[]; MICD_ERR_UNSUPPORTED when the alphabet is larger (the
 // caller then parses again into the full 65536-entry array).
-__device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, int32_t *norm,
+template <typename NormT>
+__device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *norm,
                                       uint32_t *symbol_len_out, uint32_t *tl_out, uint32_t *consumed,
                                       uint32_t norm_cap) {
     uint32_t charnum = 0;
@@ -320,7 +322,7 @@ __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, int32_t *n
         else { remaining -= count; got_total += count; }
         if (charnum > MIC_MAXSYM) return MICD_ERR_CORRUPT;
         if (charnum >= norm_cap) return MICD_ERR_UNSUPPORTED;
-        norm[charnum & 0xffff] = count;
+        norm[charnum & 0xffff] = (NormT)count;
         charnum++;
         previous0 = (count == 0);
         while (remaining < threshold) {

@@ -1,0 +1,331 @@
+// mic_tables.hip -- per-unit FSE table kernels (encode and decode side), one work-group of 1024
+// threads per unit.
+//
+//   k_enc_tables_wg  histogram scan -> gates -> tableLog -> normalise -> NCount header -> CTable
+//                    (fse2state.go:22-52; fsecompressu16.go:465-571, :191-289, :329-431)
+//   k_dec_tables_wg  prefix / flavour -> NCount parse -> decode table
+//                    (fse2state.go:102-116; fsedecompressu16.go:48-263; ransu16.go:77-135)
+//
+// What runs where: normalisation, the symbol prefix sums, the symbol spread and the slot
+// numbering are data-parallel (mic_tables_par.h); the NCount header is a variable-width bit
+// packing whose 32-bit accumulator wraps exactly like the reference's (fsecompressu16.go:260-262)
+// and stays on one lane, reading norm[] from LDS.  "Small" units (alphabet <= 8192 symbols,
+// tableLog <= 13: every 8..12-bit image) keep all scratch in 70 KiB of LDS as 16-bit values, two
+// work-groups per CU; anything larger (16-bit CT: 65536 symbols, tableLog 16) uses the unit's
+// HBM scratch slabs through the same code.
+#include "mic_dev.h"
+#include "mic_fse_tables.h"
+#include "mic_tables_par.h"
+#include "mic_launch.h"
+
+#define TB_SMALL_SYMS 8192
+#define TB_SMALL_TL 13
+
+// LDS carve-up shared by both kernels (bytes)
+#define TB_OFF_NORM   0                      // int16[8192]
+#define TB_OFF_FIRST  (16 * 1024)            // uint16[8192]
+#define TB_OFF_CUM    (32 * 1024)            // uint16[8192]
+#define TB_OFF_VISIT  (48 * 1024)            // uint16[8192]           (small units only)
+#define TB_OFF_BITMAP (64 * 1024)            // uint32[2048 + 1]
+#define TB_OFF_WPREF  (64 * 1024 + 8256)     // uint32[2048 + 1]
+#define TB_OFF_BIG    (64 * 1024 + 16512)    // uint32[4096 + 2]
+#define TB_OFF_TMP    (64 * 1024 + 32960)    // uint32[128]
+#define TB_LDS_BYTES  (64 * 1024 + 32960 + 512)    // ~96.4 KiB  (1 group / CU; the small path alone would fit 2)
+
+__device__ __forceinline__ uint32_t tb_wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename NormT, typename IdxT>
+__device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT *cum_all, uint16_t *visit_pos,
+                                uint32_t *bitmap, uint32_t *wprefix, uint32_t *big_list, uint32_t *s_tmp,
+                                uint32_t *s_misc, uint32_t n, uint32_t symbol_len, uint32_t tl) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t size = 1u << tl;
+    const uint32_t *hist = u.hist;
+    // ---- normalise, primary method (fsecompressu16.go:524-571), one symbol per thread -----------
+    {
+        const uint64_t scale = 62 - (uint64_t)tl;
+        const uint64_t step = (1ull << 62) / (uint64_t)n;
+        const uint64_t v_step = 1ull << (scale - 20);
+        const uint32_t low_threshold = n >> tl;
+        uint32_t used = 0;                        // sum of proba (and 1 per low-prob symbol)
+        uint32_t best_p = 0, best_s = 0;          // first symbol with the largest proba
+        for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) {
+            const uint32_t cnt = hist[s];
+            int32_t nv;
+            if (cnt == 0) nv = 0;
+            else if (cnt <= low_threshold) { nv = -1; used += 1; }
+            else {
+                int32_t proba = (int32_t)(((uint64_t)cnt * step) >> scale);
+                if (proba < 8) {
+                    const uint64_t rest_to_beat = v_step * (uint64_t)mic_rtb_table[proba];
+                    const uint64_t v = (uint64_t)cnt * step - ((uint64_t)proba << scale);
+                    if (v > rest_to_beat) proba++;
+                }
+                nv = proba; used += (uint32_t)proba;
+                if ((uint32_t)proba > best_p) { best_p = (uint32_t)proba; best_s = s; }   // s grows: first max kept
+            }
+            norm[s] = (NormT)nv;
+        }
+        // reduce: sum(used); argmax(best_p) with the smallest symbol index on ties
+        uint32_t sum = used;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+        // key = proba << 17 | (65536 - s)  -> larger proba wins, then smaller s   (proba <= 65536 -> use 64 bit)
+        unsigned long long key = ((unsigned long long)best_p << 20) | (unsigned long long)(0xFFFFF - best_s);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_xor((long long)key, d);
+            key = key > o ? key : o;
+        }
+        __syncthreads();
+        if (lane == 0) { s_tmp[wave] = sum; ((unsigned long long *)(s_tmp + 32))[wave] = key; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0; unsigned long long k = 0;
+            for (int w = 0; w < TP_WAVES; w++) { tot += s_tmp[w]; const unsigned long long o = ((unsigned long long *)(s_tmp + 32))[w]; k = k > o ? k : o; }
+            const int32_t still = (int32_t)size - (int32_t)tot;
+            const uint32_t largest_p = (uint32_t)(k >> 20);
+            const uint32_t largest = largest_p ? (0xFFFFF - (uint32_t)(k & 0xFFFFF)) : 0u;   // no proba > 0: largest stays 0
+            int rc = MICD_OK; uint32_t second = 0;
+            if (-still >= ((int32_t)norm[largest] >> 1)) second = 1;                           // corner case -> normalizeCount2
+            else norm[largest] = (NormT)((int32_t)norm[largest] + still);
+            s_misc[2] = second; s_misc[3] = (uint32_t)rc;
+        }
+        __syncthreads();
+        if (s_misc[2]) {                                    // rare: serial secondary method on the HBM arrays
+            if (tid == 0) s_misc[3] = (uint32_t)mic_normalize_count2(u.hist, u.norm, symbol_len, n, tl);
+            __threadfence_block();
+            __syncthreads();
+            if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
+            if ((void *)norm != (void *)u.norm)
+                for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) norm[s] = (NormT)u.norm[s];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- NCount header (one lane; fsecompressu16.go:191-289) ----------------------------------------
+    if (tid == 0) {
+        int rc = MICD_OK;
+        uint32_t hdr = 0;
+        if (u.blob_cap < 6 + 8) rc = MICD_ERR_CAPACITY;
+        else rc = mic_write_ncount(norm, symbol_len, tl, u.blob + 6, u.blob_cap - 6, &hdr);
+        if (rc == MICD_OK) {
+            u.hdr_len = hdr;
+            for (int k = 0; k < 8; k++) u.blob[6 + hdr + k] = 0;      // k_enc_tans_wg ORs into the first stream word
+        }
+        s_misc[3] = (uint32_t)rc;
+    }
+    __syncthreads();
+    if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
+    // ---- CTable: stateTable via the parallel spread, symbolTT per symbol ------------------------------
+    TpScratch<NormT, IdxT> S;
+    S.norm = norm; S.first_visit = first_visit; S.cum_all = cum_all; S.visit_pos = visit_pos;
+    S.bitmap = bitmap; S.wprefix = wprefix; S.big_list = big_list; S.s_tmp = s_tmp;
+    uint32_t *state_tab = u.state_tab;
+    const int rc = tp_build(S, symbol_len, tl, [&](uint32_t p, uint32_t s, uint32_t r, uint32_t) {
+        state_tab[(uint32_t)cum_all[s] + r] = size + p;                  // fsecompressu16.go:398-402
+    });
+    if (rc != MICD_OK) { if (tid == 0) u.status = rc; return; }
+    uint32_t zb = 0;
+    const uint32_t tlv = (tl << 16) - size;
+    const int32_t large_limit = (int32_t)(size >> 1);
+    for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) {           // fsecompressu16.go:411-424
+        const int32_t v = (int32_t)norm[s];
+        if (v == 0) continue;
+        const int32_t total = (int32_t)(uint32_t)cum_all[s];
+        if (v > large_limit) zb = 1;
+        if (v == -1 || v == 1) { u.tt_nb[s] = tlv; u.tt_find[s] = total - 1; }
+        else {
+            const uint32_t max_bits_out = tl - mic_high_bits((uint32_t)(v - 1));
+            u.tt_nb[s] = (max_bits_out << 16) - ((uint32_t)v << max_bits_out);
+            u.tt_find[s] = total - v;
+        }
+    }
+    if (__syncthreads_or((int)zb)) { if (tid == 0) u.zero_bits = 1; }
+    else if (tid == 0) u.zero_bits = 0;
+}
+
+__global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_misc[8];
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
+    // ---- histogram scan: symbolLen and maxCount (fsecompressu16.go:438-462) -------------------------
+    uint32_t m = 0, sl = 0;
+    for (uint32_t i = tid; i <= MIC_MAXSYM; i += TP_THREADS) {
+        const uint32_t c = u.hist[i];
+        if (c) { m = max(m, c); sl = max(sl, i + 1); }
+    }
+    m = tb_wave_max(m); sl = tb_wave_max(sl);
+    if (lane == 0) { s_tmp[wave] = m; s_tmp[16 + wave] = sl; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mm = 0, ss = 0;
+        for (int w = 0; w < TP_WAVES; w++) { mm = max(mm, s_tmp[w]); ss = max(ss, s_tmp[16 + w]); }
+        const uint32_t n = u.ntok;
+        u.max_count = mm; u.symbol_len = ss;
+        int rc = MICD_OK;
+        // gate order of FSECompressU16* (fse2state.go:23-42); the flavour's length gate is applied in k_enc_tans_wg
+        if (n <= 1) rc = MICD_ERR_INCOMPRESSIBLE;
+        else if (mm == n) rc = MICD_ERR_USE_RLE;
+        else if (mm == 1 || mm < (n >> 15)) rc = MICD_ERR_INCOMPRESSIBLE;
+        uint32_t tl = 0;
+        if (rc == MICD_OK) { tl = mic_optimal_table_log(n, ss); u.table_log = tl; }
+        else u.status = rc;
+        s_misc[0] = (uint32_t)rc; s_misc[1] = tl; s_misc[4] = ss; s_misc[5] = n;
+    }
+    __syncthreads();
+    if ((int)s_misc[0] != MICD_OK) return;
+    const uint32_t tl = s_misc[1], symbol_len = s_misc[4], n = s_misc[5];
+    uint32_t *bitmap = (uint32_t *)(s_raw + TB_OFF_BITMAP), *wprefix = (uint32_t *)(s_raw + TB_OFF_WPREF), *big = (uint32_t *)(s_raw + TB_OFF_BIG);
+    if (symbol_len <= TB_SMALL_SYMS && tl <= TB_SMALL_TL) {
+        enc_tables_body<int16_t, uint16_t>(u, (int16_t *)(s_raw + TB_OFF_NORM), (uint16_t *)(s_raw + TB_OFF_FIRST),
+                                           (uint16_t *)(s_raw + TB_OFF_CUM), (uint16_t *)(s_raw + TB_OFF_VISIT),
+                                           bitmap, wprefix, big, s_tmp, s_misc, n, symbol_len, tl);
+    } else {
+        // HBM scratch: norm[] itself, cumul[] for the first visits, hist[] (dead after normalisation) for cum_all,
+        // tab_sym[] for the visit sequence
+        enc_tables_body<int32_t, uint32_t>(u, u.norm, (uint32_t *)u.cumul, (uint32_t *)u.hist, u.tab_sym,
+                                           bitmap, wprefix, big, s_tmp, s_misc, n, symbol_len, tl);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+#define DT_STAGE 8192     // bytes of the blob staged in LDS for the header parse (aliases the visit/bitmap area)
+
+template <typename NormT, typename IdxT>
+__device__ void dec_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT *cum_all, uint16_t *visit_pos,
+                                uint32_t *bitmap, uint32_t *wprefix, uint32_t *big_list, uint32_t *s_tmp,
+                                uint32_t symbol_len, uint32_t tl, uint32_t flavour) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t size = 1u << tl;
+    uint32_t *dt = u.tt_nb; uint16_t *ds = u.tab_sym;
+    uint32_t bad = 0, zb = 0;
+    const int32_t large_limit = (int32_t)(size >> 1);
+    for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) if ((int32_t)norm[s] >= large_limit) zb = 1;   // fsedecompressu16.go:214-216
+    if (flavour == 108) {
+        // buildRansDecTable (ransu16.go:77-135): slots filled in symbol order, positives first, then the -1 symbols
+        uint32_t carry_pos = 0, carry_low = 0;
+        for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
+            const uint32_t s = base + tid;
+            const int32_t v = (s < symbol_len) ? (int32_t)norm[s] : 0;
+            uint32_t tot;
+            const uint32_t ex = tp_block_excl((v > 0 ? (uint32_t)v : 0u) | ((v == -1 ? 1u : 0u) << 20), s_tmp, &tot);
+            if (s < symbol_len) { first_visit[s] = (IdxT)(v == -1 ? carry_low + (ex >> 20) : carry_pos + (ex & 0xFFFFF)); }
+            carry_pos += tot & 0xFFFFF; carry_low += tot >> 20;
+        }
+        __syncthreads();
+        if (carry_pos + carry_low != size) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+        for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) {
+            const int32_t v = (int32_t)norm[s];
+            if (v == -1) { const uint32_t slot = carry_pos + (uint32_t)first_visit[s]; ds[slot] = (uint16_t)s; dt[slot] = 0u | (tl << 16); }
+        }
+        // positives: one thread per symbol walks its slots (long runs are rare and short relative to the table)
+        for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) {
+            const int32_t v = (int32_t)norm[s];
+            if (v <= 0) continue;
+            const uint32_t a = (uint32_t)first_visit[s];
+            for (uint32_t j = 0; j < (uint32_t)v; j++) {
+                const uint32_t x_next = (uint32_t)v + j;
+                const uint32_t nb = tl - mic_high_bits(x_next);
+                ds[a + j] = (uint16_t)s; dt[a + j] = ((x_next << nb) - size) | (nb << 16);
+            }
+        }
+    } else {
+        TpScratch<NormT, IdxT> S;
+        S.norm = norm; S.first_visit = first_visit; S.cum_all = cum_all; S.visit_pos = visit_pos;
+        S.bitmap = bitmap; S.wprefix = wprefix; S.big_list = big_list; S.s_tmp = s_tmp;
+        const int rc = tp_build(S, symbol_len, tl, [&](uint32_t p, uint32_t s, uint32_t r, uint32_t slots) {
+            const uint32_t next = slots + r;                              // symbolNext[s]++ in table order, :244-246
+            const uint32_t nb = tl - mic_high_bits(next);
+            const uint32_t ns = (next << nb) - size;
+            if (ns >= size || (ns == p && nb == 0)) bad = 1;              // :250-256
+            ds[p] = (uint16_t)s; dt[p] = ns | (nb << 16);
+        });
+        if (rc != MICD_OK) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+    }
+    const int anybad = __syncthreads_or((int)bad);
+    const int anyzb = __syncthreads_or((int)zb);
+    if (tid == 0) { if (anybad) u.status = MICD_ERR_CORRUPT; u.zero_bits = anyzb ? 1u : 0u; }
+}
+
+__global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_misc[8];
+    MicUnit &u = units[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t len = u.comp_len;
+    uint8_t *s_in = s_raw + TB_OFF_VISIT;                                 // staged blob head; dead before the spread starts
+    int16_t *norm16 = (int16_t *)(s_raw + TB_OFF_NORM);
+    uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
+    if (u.comp_in) for (uint32_t i = tid; i < len && i < DT_STAGE; i += TP_THREADS) s_in[i] = u.comp_in[i];
+    __syncthreads();
+    if (tid == 0) {
+        u.status = MICD_OK; u.ntok = 0;
+        int rc = MICD_OK;
+        uint32_t flavour = 1, count = 0, off = 0, used = 0, symbol_len = 0, tl = 0, small = 0;
+        do {
+            if (u.w <= 0 || u.h <= 0 || !u.comp_in) { rc = MICD_ERR_ARGS; break; }
+            if (len >= 2 && s_in[0] == 0xFF) {                             // FSEDecompressU16Auto, fse2state.go:102-116
+                if (s_in[1] == 0x84) flavour = 8;
+                else if (s_in[1] == 0x08) flavour = 108;
+                else if (s_in[1] == 0x04) flavour = 4;
+                else if (s_in[1] == 0x02) flavour = 2;
+            }
+            if (flavour != 1) {
+                if (len < 6) { rc = MICD_ERR_CORRUPT; break; }
+                count = (uint32_t)s_in[2] | ((uint32_t)s_in[3] << 8) | ((uint32_t)s_in[4] << 16) | ((uint32_t)s_in[5] << 24);
+                off = 6;
+                if (count > u.tok_cap) { rc = MICD_ERR_CORRUPT; break; }
+            }
+            // Parse from the staged bytes into 16-bit LDS norm when that is certain to be identical:
+            // the whole blob is staged, or the header ends well inside the stage.
+            rc = MICD_ERR_UNSUPPORTED;
+            if (len <= DT_STAGE) rc = mic_read_ncount(s_in + off, len - off, norm16, &symbol_len, &tl, &used, TB_SMALL_SYMS);
+            else {
+                rc = mic_read_ncount(s_in + off, DT_STAGE - off, norm16, &symbol_len, &tl, &used, TB_SMALL_SYMS);
+                if (!(rc == MICD_OK && used + 8 < DT_STAGE - off)) rc = MICD_ERR_UNSUPPORTED;
+            }
+            if (rc == MICD_OK && tl <= TB_SMALL_TL) small = 1;
+            else if (rc == MICD_OK && tl > TB_SMALL_TL) {                  // widen into the HBM norm[] for the large path
+                for (uint32_t s = 0; s < symbol_len; s++) u.norm[s] = norm16[s];
+            } else {
+                rc = mic_read_ncount(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
+            }
+        } while (0);
+        if (rc == MICD_OK) { u.flavour = flavour; u.count = count; u.symbol_len = symbol_len; u.table_log = tl; u.bits_off = off + used; }
+        else u.status = rc;
+        s_misc[0] = (uint32_t)rc; s_misc[1] = tl; s_misc[2] = symbol_len; s_misc[3] = flavour; s_misc[4] = small;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if ((int)s_misc[0] != MICD_OK) return;
+    const uint32_t tl = s_misc[1], symbol_len = s_misc[2], flavour = s_misc[3];
+    uint32_t *bitmap = (uint32_t *)(s_raw + TB_OFF_BITMAP), *wprefix = (uint32_t *)(s_raw + TB_OFF_WPREF), *big = (uint32_t *)(s_raw + TB_OFF_BIG);
+    if (s_misc[4]) {
+        dec_tables_body<int16_t, uint16_t>(u, norm16, (uint16_t *)(s_raw + TB_OFF_FIRST), (uint16_t *)(s_raw + TB_OFF_CUM),
+                                           (uint16_t *)(s_raw + TB_OFF_VISIT), bitmap, wprefix, big, s_tmp, symbol_len, tl, flavour);
+    } else {
+        // HBM scratch: cumul[] first visits, hist[] cum_all, state_tab[] (u32, first half used as u16) visit sequence
+        dec_tables_body<int32_t, uint32_t>(u, u.norm, (uint32_t *)u.cumul, (uint32_t *)u.hist, (uint16_t *)u.state_tab,
+                                           bitmap, wprefix, big, s_tmp, symbol_len, tl, flavour);
+    }
+}
+
+void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void *)k_enc_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); done = true; }
+    hipLaunchKernelGGL(k_enc_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
+}
+void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void *)k_dec_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); done = true; }
+    hipLaunchKernelGGL(k_dec_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
+}
