@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 #define TK_PPT 2
 #define TK_SPT 4
 #define TK_WIN (TK_THREADS * TK_SPT)
+#define TK_HWIN 16384
 
 __device__ __forceinline__ uint32_t tk_wave_incl_add(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -154,6 +155,9 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     __shared__ uint16_t xs[TK_WIN + 16];          // [0..5] = 6 symbols before the tile, [6..] = new symbols
     __shared__ uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
     __shared__ uint32_t s_ovf;
+    // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
+    // the delta threshold takes almost every token; the rest goes to HBM atomics
+    __shared__ uint32_t s_hist[TK_HWIN];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; }
     const int depth = mic_len16(u.max_value);
@@ -174,7 +178,15 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     uint32_t outp = 1;               // tokens written so far; tok[0] = delimiter (rlecompressu16.go:21)
     uint32_t run1 = 0, str1 = 0;     // index+1 of the first symbol of the current run / diff stretch (0 = none)
     uint32_t last_same = 0;
-    if (tid == 0) { if (cap > 0) tok[0] = (uint16_t)delim; xs[5] = u.max_value; }
+    const uint32_t hlo = (delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
+    uint32_t *ghist = u.hist;
+    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
+    __syncthreads();
+    auto count_tok = [&](uint32_t v) {
+        const uint32_t d = v - hlo;
+        if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u); else atomicAdd(&ghist[v], 1u);
+    };
+    if (tid == 0) { if (cap > 0) { tok[0] = (uint16_t)delim; count_tok(delim); } xs[5] = u.max_value; }
     __syncthreads();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
@@ -332,13 +344,13 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                 if (same_bits & (1u << q)) {
                     const uint32_t k = kk[q];
                     if (k > 3 && (k - 3) % c == 0) {
-                        if (pos + 1 < cap) { tok[pos] = (uint16_t)c; tok[pos + 1] = (uint16_t)xv; } else ovf = true;
+                        if (pos + 1 < cap) { tok[pos] = (uint16_t)c; tok[pos + 1] = (uint16_t)xv; count_tok(c); count_tok(xv); } else ovf = true;
                         pos += 2;
                     }
                     const bool last = !ex1 || xv != xs[idx + 1];
                     if (last) {
                         const uint32_t rem = (k - 3) % c + 3;
-                        if (pos + 1 < cap) { tok[pos] = (uint16_t)rem; tok[pos + 1] = (uint16_t)xv; } else ovf = true;
+                        if (pos + 1 < cap) { tok[pos] = (uint16_t)rem; tok[pos + 1] = (uint16_t)xv; count_tok(rem); count_tok(xv); } else ovf = true;
                         pos += 2;
                     }
                 } else {
@@ -346,7 +358,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                     const uint32_t jm = (j - 1) % c;
                     const bool starts = (j == 1) || (jm == 0 && ex2);
                     const uint32_t lit = pos + (starts ? 1u : 0u);
-                    if (lit < cap) tok[lit] = (uint16_t)xv; else ovf = true;
+                    if (lit < cap) { tok[lit] = (uint16_t)xv; count_tok(xv); } else ovf = true;
                     pos += starts ? 2u : 1u;
                     // does the chunk end here?  next symbol: end of stream / start of a same-run / opens a chunk
                     bool same_next;
@@ -358,7 +370,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                         uint32_t qlen = jm + 1;
                         // boundary suppressed for the last two symbols of the stream: they extend the previous chunk
                         if (j - jm > 1 && !((i - (int64_t)jm + 2) < (int64_t)g1) && flush) qlen += c;
-                        if (lit >= qlen && lit - qlen < cap) tok[lit - qlen] = (uint16_t)(mid + qlen); else ovf = true;
+                        if (lit >= qlen && lit - qlen < cap) { tok[lit - qlen] = (uint16_t)(mid + qlen); count_tok(mid + qlen); } else ovf = true;
                     }
                 }
             }
@@ -383,6 +395,9 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         }
         g0 = g1;
     }
+    __syncthreads();
+    // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
+    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&ghist[hlo + i], v); }
     if (tid == 0) {
         if (s_ovf || outp > cap) u.status = MICD_ERR_CAPACITY;
         else u.ntok = outp;
@@ -859,8 +874,10 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         if (t) t->mark("k_enc_tokens_wg");
         hipLaunchKernelGGL(k_enc_tokens_wg, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
     }
-    if (t) t->mark("k_enc_hist");
-    hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
+    if (variant == 100) {
+        if (t) t->mark("k_enc_hist");
+        hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
+    }
     if (variant == 100) {
         if (t) t->mark("k_enc_tables");
         hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(256), 0, stream, d_units);
