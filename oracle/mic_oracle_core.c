@@ -103,6 +103,7 @@ static int rle_done(rle_enc *r, size_t *out_n) {
 int mico_rle_compress(const uint16_t *in, size_t n, uint16_t max_value,
                       uint16_t *out, size_t cap, size_t *out_n) {
     rle_enc r;
+    if (len16(max_value) < 4) return MICO_ERR_ARGS; /* degenerate chunking, see delta_walk */
     int rc = rle_init(&r, max_value, out, cap);
     if (rc) return rc;
     rle_put(&r, (uint16_t)(n >> 16));

@@ -138,3 +138,102 @@ def mic2_decompress(b: bytes):
     out = np.empty((n_.value, h.value, w.value), dtype=np.uint16)
     rc = lib().mico_mic2_decompress(_p(a), C.c_size_t(a.size), _p(out), C.c_size_t(out.size), C.byref(w), C.byref(h), C.byref(n_))
     return rc, (out if rc == 0 else None)
+
+
+def rle_compress(sym: np.ndarray, max_value: int) -> np.ndarray:
+    sym = np.ascontiguousarray(sym, dtype=np.uint16)
+    out = np.empty(2 * sym.size + 64, dtype=np.uint16)
+    n = C.c_size_t()
+    rc = lib().mico_rle_compress(_p(sym), C.c_size_t(sym.size), C.c_uint16(max_value), _p(out), C.c_size_t(out.size), C.byref(n))
+    if rc:
+        raise RuntimeError(f"mico_rle_compress rc={rc}")
+    return out[: n.value].copy()
+
+
+def wt53_forward(data: np.ndarray, levels: int):
+    """in-place multi-level forward transform of an int32 (rows, cols) array; returns levels applied"""
+    assert data.dtype == np.int32 and data.flags.c_contiguous
+    rows, cols = data.shape
+    applied = C.c_int()
+    rc = lib().mico_wt53_forward(_p(data), rows, cols, levels, C.byref(applied))
+    if rc:
+        raise RuntimeError(f"mico_wt53_forward rc={rc}")
+    return applied.value
+
+
+def wt53_inverse(data: np.ndarray, levels: int) -> None:
+    assert data.dtype == np.int32 and data.flags.c_contiguous
+    rows, cols = data.shape
+    rc = lib().mico_wt53_inverse(_p(data), rows, cols, levels)
+    if rc:
+        raise RuntimeError(f"mico_wt53_inverse rc={rc}")
+
+
+def wavelet_v2_compress(px: np.ndarray, max_value: int, levels: int = 5):
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    rows, cols = px.shape
+    out = np.empty(px.size * 6 + 200000, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_wavelet_v2_compress(_p(px), rows, cols, C.c_uint16(max_value), levels, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def wavelet_v2_decompress(b: bytes):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    r, c = C.c_int(), C.c_int()
+    rc = lib().mico_wavelet_v2_decompress(_p(a), C.c_size_t(a.size), None, C.c_size_t(0), C.byref(r), C.byref(c))
+    if rc:
+        return rc, None
+    out = np.empty((r.value, c.value), dtype=np.uint16)
+    rc = lib().mico_wavelet_v2_decompress(_p(a), C.c_size_t(a.size), _p(out), C.c_size_t(out.size), C.byref(r), C.byref(c))
+    return rc, (out if rc == 0 else None)
+
+
+def ycocgr_forward(rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+    n = rgb.shape[0]
+    y = np.empty(n, np.uint16); co = np.empty(n, np.uint16); cg = np.empty(n, np.uint16)
+    lib().mico_ycocgr_forward(_p(rgb), n, _p(y), _p(co), _p(cg))
+    return y, co, cg
+
+
+def ycocgr_inverse(y, co, cg) -> np.ndarray:
+    n = y.size
+    rgb = np.empty((n, 3), np.uint8)
+    lib().mico_ycocgr_inverse(_p(np.ascontiguousarray(y)), _p(np.ascontiguousarray(co)), _p(np.ascontiguousarray(cg)), n, _p(rgb))
+    return rgb
+
+
+def wsi_compress_tile(rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    th, tw, _ = rgb.shape
+    out = np.empty(rgb.size * 4 + 4096, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_wsi_compress_tile(_p(rgb), tw, th, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def wsi_decompress_tile(b: bytes, tw: int, th: int):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    out = np.empty((th, tw, 3), dtype=np.uint8)
+    rc = lib().mico_wsi_decompress_tile(_p(a), C.c_size_t(a.size), tw, th, _p(out))
+    return rc, (out if rc == 0 else None)
+
+
+def wsi_compress(rgb: np.ndarray, tile_w: int = 256, tile_h: int = 256, levels: int = 0):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty(rgb.size * 6 + (1 << 20), dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_wsi_compress(_p(rgb), w, h, tile_w, tile_h, levels, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def wsi_decompress_tile_at(b: bytes, level: int, tx: int, ty: int, tile_w: int = 256, tile_h: int = 256):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    out = np.empty(tile_w * tile_h * 3, dtype=np.uint8)
+    tw, th = C.c_int(), C.c_int()
+    rc = lib().mico_wsi_decompress_tile_at(_p(a), C.c_size_t(a.size), level, tx, ty, _p(out), C.c_size_t(out.size), C.byref(tw), C.byref(th))
+    if rc:
+        return rc, None
+    return rc, out[: tw.value * th.value * 3].reshape(th.value, tw.value, 3).copy()

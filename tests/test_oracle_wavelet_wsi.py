@@ -1,0 +1,136 @@
+"""CPU tests of the oracle's WaveletV2 and MIC3/WSI restatements against the reference's own
+known answers, closed-form test inputs and published sizes.  Byte parity of these streams is
+NOT pinned by a runnable reference (the reference C covers neither) -- what pins
+them is listed in oracle/README.md."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _mr():
+    return np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
+
+
+def _ct():
+    return np.fromfile(os.path.join(GOLDEN, "CT_512_512_image.bin"), dtype="<u2").reshape(512, 512)
+
+
+# ---- 5/3 lifting: waveletu16_test.go:190-248 (closed-form inputs, odd dims) ----------------
+@pytest.mark.parametrize("rows,cols", [(8, 8), (15, 17), (63, 65), (64, 64), (1, 9), (9, 1), (2, 2), (3, 5)])
+@pytest.mark.parametrize("levels", [1, 3, 5, 8])
+def test_wt53_round_trip_closed_form(mico, synth, rows, cols, levels):
+    src = synth.closed_form(rows * cols, 131, 7, 65536).astype(np.int32).reshape(rows, cols)
+    data = src.copy()
+    applied = mico.wt53_forward(data, levels)
+    assert applied <= levels
+    mico.wt53_inverse(data, applied)
+    assert np.array_equal(data, src)
+
+
+def test_wt53_one_level_matches_direct_formula(mico, synth):
+    """d[i] = x[2i+1] - ((x[2i]+x[2i+2])>>1), s[i] = x[2i] + ((d[i-1]+d[i]+2)>>2) with the
+    reference's boundary rules (waveletu16.go:26-74), checked on a single row."""
+    x = synth.closed_form(18, 97, 13, 4096).astype(np.int64)
+    n = x.size
+    d = [int(x[2 * i + 1] - ((x[2 * i] + (x[2 * i + 2] if 2 * i + 2 < n else x[2 * i])) >> 1)) for i in range(n // 2)]
+    s = []
+    for i in range((n + 1) // 2):
+        dr = d[i] if 2 * i + 1 < n else (d[i - 1] if i > 0 else 0)
+        dl = d[i - 1] if i > 0 else dr
+        s.append(int(x[2 * i] + ((dl + dr + 2) >> 2)))
+    data = np.zeros((2, n), dtype=np.int32)
+    data[0] = x; data[1] = x                       # two equal rows: the column pass leaves low = row, high = 0
+    mico.wt53_forward(data, 1)
+    assert list(data[0, : len(s)]) == s and list(data[0, len(s):]) == d
+    assert not data[1].any()
+
+
+@pytest.mark.parametrize("name,ratio", [("MR", 2.381), ("CT", 1.669)])
+def test_wavelet_v2_published_ratio(mico, name, ratio):
+    """results/20260518-054951/06-wavelet-simd.txt: WaveletV2 (5 levels) ratios MR 2.381, CT 1.669."""
+    img = _mr() if name == "MR" else _ct()
+    rc, blob = mico.wavelet_v2_compress(img, int(img.max()), 5)
+    assert rc == 0
+    assert abs(img.size * 2 / len(blob) - ratio) < 0.0015
+    assert blob[10] == 5 and blob[11:13] == bytes([0xFF, 0x04])
+    rc, px = mico.wavelet_v2_decompress(blob)
+    assert rc == 0 and np.array_equal(px, img)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [(15, 17, 2), (63, 65, 5), (130, 70, 8), (100, 3, 5)])
+def test_wavelet_v2_round_trip_odd_dims(mico, synth, rows, cols, levels):
+    img = synth.xr_like(cols=cols, rows=rows, depth=12, seed=rows + cols)
+    rc, blob = mico.wavelet_v2_compress(img, 4095, levels)
+    if rc != 0:
+        assert rc in (mico.ERR_INCOMPRESSIBLE, -8)          # tiny inputs: the 4-state FSE has no fallback
+        return
+    assert int.from_bytes(blob[0:4], "little") == rows and int.from_bytes(blob[4:8], "little") == cols
+    rc, px = mico.wavelet_v2_decompress(blob)
+    assert rc == 0 and np.array_equal(px, img)
+
+
+# ---- YCoCg-R: wsi_test.go:170-215 ------------------------------------------------------------
+def test_ycocgr_known_answer(mico):
+    y, co, cg = mico.ycocgr_forward(np.array([[200, 100, 50]], dtype=np.uint8))
+    assert (int(y[0]), int(co[0]), int(cg[0])) == (112, 300, 49)
+
+
+def test_ycocgr_exhaustive_round_trip(mico):
+    """All 2^24 colours (wsi_test.go:170-195), in 16 slabs."""
+    g, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    for r0 in range(0, 256, 16):
+        rgb = np.empty((16, 256, 256, 3), dtype=np.uint8)
+        rgb[..., 0] = np.arange(r0, r0 + 16, dtype=np.uint8)[:, None, None]
+        rgb[..., 1] = g[None]; rgb[..., 2] = b[None]
+        flat = rgb.reshape(-1, 3)
+        y, co, cg = mico.ycocgr_forward(flat)
+        assert y.max() <= 255 and co.max() <= 510 and cg.max() <= 510
+        assert np.array_equal(mico.ycocgr_inverse(y, co, cg), flat)
+
+
+# ---- tiles and the MIC3 container: wsi_test.go:361-603, docs/compression-results.md:167-174 -----
+def test_white_tile_is_constant_planes_and_101_bytes(mico):
+    white = np.full((256, 256, 3), 255, dtype=np.uint8)
+    rc, blob = mico.wsi_compress_tile(white)
+    assert rc == 0 and len(blob) == 12 + 3 + 1 + 1                     # Y const 255, Co/Cg const zero
+    rc, mic3 = mico.wsi_compress(white)
+    assert rc == 0 and len(mic3) == 101                                # 196608 / 101 = 1946x (published)
+    assert mic3[:4] == b"MIC3" and mic3[27] == 0x03
+    rc, tile = mico.wsi_decompress_tile_at(mic3, 0, 0, 0)
+    assert rc == 0 and np.array_equal(tile, white)
+
+
+def test_wsi_pyramid_levels_and_edge_tiles(mico, synth):
+    img = synth.wsi_like(600, 420, seed=5)
+    rc, mic3 = mico.wsi_compress(img)
+    assert rc == 0
+    nlev = int.from_bytes(mic3[28:30], "little")
+    assert nlev == 3                                                    # 600x420 -> 300x210 -> 150x105 (fits one tile)
+    dims = [(int.from_bytes(mic3[48 + 20 * i: 52 + 20 * i], "little"), int.from_bytes(mic3[52 + 20 * i: 56 + 20 * i], "little")) for i in range(nlev)]
+    assert dims == [(600, 420), (300, 210), (150, 105)]
+    assert int.from_bytes(mic3[32:40], "little") == 3 * 2 + 2 * 1 + 1
+    # level 0: reassemble from cropped tiles
+    out = np.zeros_like(img)
+    for ty in range(2):
+        for tx in range(3):
+            rc, t = mico.wsi_decompress_tile_at(mic3, 0, tx, ty)
+            assert rc == 0
+            out[ty * 256: ty * 256 + t.shape[0], tx * 256: tx * 256 + t.shape[1]] = t
+    assert np.array_equal(out, img)
+    # level 1 = 2x2 box filter with +2 rounding (wsipyramid.go:10-32)
+    a = img[:420, :600].astype(np.int32)
+    want = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) // 4).astype(np.uint8)
+    rc, t = mico.wsi_decompress_tile_at(mic3, 1, 0, 0)
+    assert rc == 0 and np.array_equal(t, want[:256, :256])
+
+
+def test_wsi_noise_plane_falls_back_to_raw(mico, synth):
+    h = synth.hash_u64(256 * 256 * 3, 77)
+    noise = (h & np.uint64(0xFF)).astype(np.uint8).reshape(256, 256, 3)
+    rc, blob = mico.wsi_compress_tile(noise)
+    assert rc == 0
+    rc, back = mico.wsi_decompress_tile(blob, 256, 256)
+    assert rc == 0 and np.array_equal(back, noise)
