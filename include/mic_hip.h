@@ -69,6 +69,19 @@ int mic_hip_compress_frame(const uint16_t *pixels, int width, int height,
 int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len,
                              uint16_t *pixels_out, int width, int height);
 
+/* ---- bare FSE stage -------------------------------------------------------------------- */
+/* Replaces FSECompressU16 (fsecompressu16.go:19), FSECompressU16TwoState (fse2state.go:22),
+ * ...FourState (fse4state.go:24), ...EightState (fse8state.go:31) and RANSCompressU16EightState
+ * (rans8state.go:31): flavour = 1, 2, 4, 8 or 108 (rANS-8).  No fallback chain: the sentinels
+ * MIC_ERR_USE_RLE / MIC_ERR_INCOMPRESSIBLE come back exactly where the Go functions return
+ * ErrUseRLE / ErrIncompressible.  out_cap >= 2*n + 200000 is always sufficient. */
+int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour,
+                             uint8_t *out, size_t out_cap, size_t *out_len);
+/* Replaces FSEDecompressU16Auto (fse2state.go:102-116): magic-byte dispatch over all five
+ * flavours.  *out_n receives the number of symbols written. */
+int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len,
+                                    uint16_t *out, size_t out_cap, size_t *out_n);
+
 /* ---- batch: many independent units in one call (one cgo crossing, one launch chain) --- */
 /* Replaces the goroutine fan-out of parallelstrips.go:77-93 / :292-321, the frame loop of
  * multiframecompress.go:186-209 and the tile worker pool of wsicompress.go:126-145. */

@@ -434,6 +434,70 @@ int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len, u
     return j.status;
 }
 
+// ---- bare FSE stage (fsecompressu16.go:19, fse2state.go:22/102, fse4state.go:24, fse8state.go:31, rans8state.go:31)
+int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!symbols || !out || !out_len) return MIC_ERR_ARGS;
+    if (!(flavour == 1 || flavour == 2 || flavour == 4 || flavour == 8 || flavour == 108)) return MIC_ERR_ARGS;
+    if (n <= 1) return MIC_ERR_INCOMPRESSIBLE;                          // first gate of every FSECompressU16* variant
+    if (n > ((size_t)1 << 30)) return MIC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    const size_t px = (n + 3) / 4 + 16;
+    if ((rc = s->ensure(1, px))) return rc;
+    if ((rc = s->io_px.reserve(n * 2 + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->io_px.p, symbols, n * 2, hipMemcpyHostToDevice, s->stream));
+    s->h_units.assign(1, MicUnit{});
+    MicUnit &u = s->h_units[0];
+    u.px_in = (const uint16_t *)s->io_px.p; u.w = (int32_t)n; u.h = 1; u.max_value = 0;
+    u.nstates = (uint16_t)flavour; u.mode = 1; u.no_fallback = 1;
+    s->fill_workspace(u, 0);
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4, s->stream));
+    mic_launch_encode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
+    HIP_TRY(hipGetLastError());
+    s->n_last = 1;
+    uint64_t offs[2]; int32_t st = 0, ns = 0; const uint8_t *d_blobs = nullptr;
+    if ((rc = session_encode_finish(s, &d_blobs, offs, &st, &ns))) return rc;
+    if (st != MIC_OK) return st;
+    const size_t len = (size_t)offs[1];
+    if (len > out_cap) return MIC_ERR_CAPACITY;
+    HIP_TRY(hipMemcpy(out, d_blobs, len, hipMemcpyDeviceToHost));
+    *out_len = len;
+    return MIC_OK;
+}
+
+int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *out, size_t out_cap, size_t *out_n) {
+    if (!in || !out || !out_n || in_len == 0) return in && in_len == 0 ? MIC_ERR_CORRUPT : MIC_ERR_ARGS;
+    if (in_len > 0xFFFFFFF0ull || out_cap > ((size_t)1 << 30)) return MIC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    const size_t px = (out_cap + 3) / 4 + 16;
+    if ((rc = s->ensure(1, px))) return rc;
+    if ((rc = s->io_comp.reserve(in_len + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->io_comp.p, in, in_len, hipMemcpyHostToDevice, s->stream));
+    s->h_units.assign(1, MicUnit{});
+    MicUnit &u = s->h_units[0];
+    u.comp_in = (const uint8_t *)s->io_comp.p; u.comp_len = (uint32_t)in_len; u.w = 1; u.h = 1; u.mode = 1;
+    s->fill_workspace(u, 0);
+    u.tok_cap = (uint32_t)std::min<size_t>(out_cap, u.tok_cap);
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
+    mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
+    HIP_TRY(hipGetLastError());
+    s->n_last = 1;
+    int32_t st = 0;
+    if ((rc = session_decode_finish(s, &st))) return rc;
+    if (st != MIC_OK) return st;
+    const size_t n = s->h_units[0].ntok;
+    if (n > out_cap) return MIC_ERR_CAPACITY;
+    if (n) HIP_TRY(hipMemcpy(out, s->h_units[0].tok, n * 2, hipMemcpyDeviceToHost));
+    *out_n = n;
+    return MIC_OK;
+}
+
 // ---- PICS (parallelstrips.go) ----------------------------------------------------------------
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
                           uint8_t *out, size_t out_cap, size_t *out_len) {

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) k_dec_tables(MicUnit *units) {
         s_flag[0] = 0;
         u.status = MICD_OK; u.ntok = 0;
         do {
-            if (u.w <= 0 || u.h <= 0 || !u.comp_in) { u.status = MICD_ERR_ARGS; break; }
+            if ((u.mode == 0 && (u.w <= 0 || u.h <= 0)) || !u.comp_in) { u.status = MICD_ERR_ARGS; break; }
             const uint8_t *b = (len <= DT_STAGE_BYTES) ? s_in : u.comp_in;   // short blobs parse entirely from LDS
             // FSEDecompressU16Auto, fse2state.go:102-116
             uint32_t flavour = 1;
@@ -179,7 +179,7 @@ struct RleIt {
 // v0: one lane expands the tokens and inverts the predictor.  grid = units, block = 64.
 __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    if (threadIdx.x != 0 || u.status != MICD_OK) return;
+    if (threadIdx.x != 0 || u.status != MICD_OK || u.mode != 0) return;
     if (u.ntok < 1) { u.status = MICD_ERR_CORRUPT; return; }
     RleIt r; r.in = u.tok; r.n = u.ntok; r.i = 1; r.c = 0; r.rec = 0; r.err = false;
     int d0 = mic_len16(u.tok[0]);                                      // rledecompressu16.go:21-25

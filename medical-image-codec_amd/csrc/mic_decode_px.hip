@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t g, uint32_t f) {
 
 __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    if (u.status != MICD_OK) return;
+    if (u.status != MICD_OK || u.mode != 0) return;
     __shared__ uint32_t s_scan[PX_WAVES + 1];
     __shared__ uint32_t s_fn[PX_WAVES + 1];
     __shared__ uint32_t s_misc[8];

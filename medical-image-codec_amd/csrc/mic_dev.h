@@ -31,7 +31,9 @@ struct MicUnit {
     uint32_t        comp_len;
     int32_t         w, h;
     uint16_t        max_value;
-    uint16_t        nstates;  // encode: requested flavour 2/4/8
+    uint16_t        nstates;  // encode: requested flavour 1/2/4/8, 108 = rANS-8
+    uint32_t        mode;     // 0 = frame (Delta+RLE around the FSE stage), 1 = bare FSE: px_in / px_out hold u16 symbols, w = count
+    uint32_t        no_fallback; // 1 = FSECompressU16* semantics (no N -> ... -> 1 chain)
     // ---- per-unit workspace (HBM) ------------------------------------------------
     uint16_t *tok;            // RLE token stream (encode: produced, decode: FSE output)
     uint32_t  tok_cap;

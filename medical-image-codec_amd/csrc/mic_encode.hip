@@ -79,7 +79,7 @@ struct RleTok {
 // v0: one lane walks the unit.  grid = units, block = 64.
 __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || u.mode != 0) return;
     u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0;
     int depth = mic_len16(u.max_value);
     if (u.w <= 0 || u.h <= 0) { u.status = MICD_ERR_ARGS; return; }
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (u.mode != 0) return;                                  // bare-FSE units bring their own symbols
     if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; }
     const int depth = mic_len16(u.max_value);
     if (u.w <= 0 || u.h <= 0) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
@@ -405,6 +406,26 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Bare FSE units (FSECompressU16 / TwoState / FourState / EightState, RANSCompressU16EightState:
+// fsecompressu16.go:19, fse2state.go:22, fse4state.go:24, fse8state.go:31, rans8state.go:31):
+// the caller's symbols are the token stream.  grid = (64, units), block = 256.
+__global__ void __launch_bounds__(256) k_enc_symbols(MicUnit *units) {
+    MicUnit &u = units[blockIdx.y];
+    if (u.mode != 1) return;
+    const uint32_t n = (uint32_t)u.w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u.status = (n <= u.tok_cap) ? MICD_OK : MICD_ERR_CAPACITY; u.ntok = (n <= u.tok_cap) ? n : 0; u.blob_len = 0; u.nstates_used = 0;
+    }
+    if (n > u.tok_cap) return;
+    const uint16_t *src = u.px_in; uint16_t *tok = u.tok; uint32_t *hist = u.hist;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint16_t v = src[i];
+        tok[i] = v;
+        atomicAdd(&hist[v], 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Histogram of the token stream.  grid = (blocks_per_unit, units), block = 256.
 // hist must be zero on entry (the launcher memsets the workspace slab).
 __global__ void __launch_bounds__(256) k_enc_hist(MicUnit *units) {
@@ -502,6 +523,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (threadIdx.x != 0 || u.status != MICD_OK) return;
     if (u.nstates_used != 0) return;                                      // k_enc_tans_wg already wrote it
+    if (u.nstates == 108) { u.status = MICD_ERR_UNSUPPORTED; return; }     // rANS encode exists only in k_enc_tans_wg
     const uint32_t n = u.ntok;
     const uint16_t *src = u.tok;
     const uint32_t tl = u.table_log;
@@ -545,7 +567,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
             return;
         }
         u.status = rc;                                                  // error of the last attempt
-        if (lanes == 1) return;
+        if (lanes == 1 || u.no_fallback) return;
         if (rc == MICD_ERR_CAPACITY) return;
         u.status = MICD_OK;                                             // try the next flavour
     }
@@ -599,7 +621,7 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 
 // Thread t (t = 0 encodes first) owns the 32-token blocks [b_lo, b_hi); all N chains of those
 // tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
-template <int N>
+template <int N, bool RANS>
 __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
@@ -616,9 +638,29 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
     const uint32_t b_hi = (tid * per < nblk) ? nblk - tid * per : 0;
     const uint32_t b_lo = (b_hi > per) ? b_hi - per : 0;
     // ---- 1. speculative walk from the guessed state 2^tl --------------------------------------
+    // One coding step.  tANS: cStateU16.encode (fsecompressu16.go:95-100), state in [2^tl, 2^(tl+1)).
+    // rANS: ransEncodeStep (ransu16.go:187-197) on xL = x + 2^tl with the per-symbol record
+    // tt_nb = freq | k0 << 20, tt_find = bias; both emit (state & mask(nb), nb) and both forget
+    // the old state down to one of `freq` values, which is what makes the walks merge.
+    auto step = [&](uint32_t state, uint32_t sy, uint32_t &nb_out) -> uint32_t {
+        if (RANS) {
+            const uint32_t e = tt_nb[sy], freq = e & 0xFFFFF, k0 = e >> 20;
+            const uint32_t k = k0 - ((state < (freq << k0)) ? 1u : 0u);
+            nb_out = k;
+            return size + (uint32_t)tt_find[sy] + ((state >> k) - freq);
+        } else {
+            const uint32_t nb = (state + tt_nb[sy]) >> 16;
+            nb_out = nb;
+            return size + s_stab[(int32_t)(state >> nb) + tt_find[sy]];
+        }
+    };
+    auto nbits = [&](uint32_t state, uint32_t sy) -> uint32_t {
+        if (RANS) { const uint32_t e = tt_nb[sy], freq = e & 0xFFFFF, k0 = e >> 20; return k0 - ((state < (freq << k0)) ? 1u : 0u); }
+        return (state + tt_nb[sy]) >> 16;
+    };
     uint32_t st[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) st[k] = size;
+    for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
     for (uint32_t b = b_hi; b > b_lo; b--) {
         const uint32_t base = (b - 1) * TE_BLK;
         const TeBlk tk = te_load(src + base);
@@ -630,8 +672,8 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
                 const uint32_t sy = te_get(tk, j);
                 const int k = j & (N - 1);
                 te_set(rec, j, st[k] - size);
-                const uint32_t nb = (st[k] + tt_nb[sy]) >> 16;
-                st[k] = size + s_stab[(int32_t)(st[k] >> nb) + tt_find[sy]];
+                uint32_t nb;
+                st[k] = step(st[k], sy, nb);
             } else te_set(rec, j, 0);
         }
         te_store(stv + base, rec);
@@ -671,8 +713,8 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
                             else {
                                 const uint32_t sy = te_get(tk, j);
                                 te_set(rec, j, st2[k] - size);
-                                const uint32_t nb = (st2[k] + tt_nb[sy]) >> 16;
-                                st2[k] = size + s_stab[(int32_t)(st2[k] >> nb) + tt_find[sy]];
+                                uint32_t nb;
+                                st2[k] = step(st2[k], sy, nb);
                             }
                         }
                     }
@@ -708,7 +750,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
         const TeBlk rec = te_load(stv + base);
 #pragma unroll
         for (int j = TE_BLK - 1; j >= 0; j--)
-            if (base + (uint32_t)j < n) mybits += (te_get(rec, j) + size + tt_nb[te_get(tk, j)]) >> 16;
+            if (base + (uint32_t)j < n) mybits += nbits(te_get(rec, j) + size, te_get(tk, j));
     }
     const uint32_t incl = tk_wave_incl_add(mybits, lane);
     if (lane == 63) s_scan[wave] = incl;
@@ -745,7 +787,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
         for (int j = TE_BLK - 1; j >= 0; j--) {
             if (base + (uint32_t)j < n) {
                 const uint32_t stt = te_get(rec, j) + size;
-                const uint32_t nb = (stt + tt_nb[te_get(tk, j)]) >> 16;
+                const uint32_t nb = nbits(stt, te_get(tk, j));
                 acc |= (uint64_t)(stt & ((1u << nb) - 1u)) << filled;   // nb <= 16
                 filled += nb;
                 if (filled >= 32) {
@@ -793,27 +835,30 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
-    for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
+    if (u.nstates != 108) for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
-    for (uint32_t lanes = u.nstates; lanes >= 1; lanes >>= 1) {
-        // length gates: fse8state.go:32, fse4state.go:25, fse2state.go:23, fsecompressu16.go:20
+    const bool rans = u.nstates == 108;                                          // rans8state.go: 8 lanes, magic FF 08
+    const bool single = u.no_fallback != 0;
+    for (uint32_t lanes = rans ? 8u : u.nstates; lanes >= 1; lanes >>= 1) {
+        // length gates: fse8state.go:32, fse4state.go:25, fse2state.go:23, fsecompressu16.go:20, rans8state.go:32
         int rc = MICD_OK;
         if (n <= lanes - 1 || n <= 1) rc = MICD_ERR_INCOMPRESSIBLE;
         else if (n <= 2 && lanes <= 2) rc = MICD_ERR_INTERNAL;                   // "src too small"
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
-            if (lanes == 8) te_encode<8>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else if (lanes == 4) te_encode<4>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else if (lanes == 2) te_encode<2>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else te_encode<1>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            if (rans) te_encode<8, true>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else if (lanes == 8) te_encode<8, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else if (lanes == 4) te_encode<4, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else if (lanes == 2) te_encode<2, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            else te_encode<1, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
         }
         __syncthreads();
         if (rc == MICD_OK) {
             if (tid == 0) {
                 if (lanes != 1) {
                     u.blob[0] = 0xFF;
-                    u.blob[1] = lanes == 2 ? 0x02 : lanes == 4 ? 0x04 : 0x84;
+                    u.blob[1] = rans ? 0x08 : lanes == 2 ? 0x02 : lanes == 4 ? 0x04 : 0x84;
                     u.blob[2] = (uint8_t)n; u.blob[3] = (uint8_t)(n >> 8);
                     u.blob[4] = (uint8_t)(n >> 16); u.blob[5] = (uint8_t)(n >> 24);
                 }
@@ -824,7 +869,7 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint
             return;
         }
         if (tid == 0) { u.count = (uint32_t)rc; u.bits_off = total_bytes; u.flavour = lanes; }   // probe: why the attempt failed
-        if (lanes == 1 || rc == MICD_ERR_CAPACITY) { if (tid == 0) u.status = rc; return; }
+        if (lanes == 1 || rc == MICD_ERR_CAPACITY || single) { if (tid == 0) u.status = rc; return; }
         __syncthreads();
     }
 }
@@ -867,6 +912,8 @@ __global__ void __launch_bounds__(1024) k_scan_lens(const MicUnit *units, int n,
 // ------------------------------------------------------------------------------------------
 // launchers
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
+    if (t) t->mark("k_enc_symbols");
+    hipLaunchKernelGGL(k_enc_symbols, dim3(64, n), dim3(256), 0, stream, d_units);
     if (variant == 100) {
         if (t) t->mark("k_enc_tokens_serial");
         hipLaunchKernelGGL(k_enc_tokens_serial, dim3(n), dim3(64), 0, stream, d_units);

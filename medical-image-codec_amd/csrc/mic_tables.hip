@@ -122,6 +122,31 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     }
     __syncthreads();
     if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
+    if (u.nstates == 108) {
+        // buildRansEncTable (ransu16.go:139-180): bias = cumulative frequency, positives in symbol order, then the
+        // low-probability symbols; record = freq | k0 << 20 in tt_nb, bias in tt_find.  No state table.
+        uint32_t carry_pos = 0, carry_low = 0;
+        for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
+            const uint32_t s2 = base + tid;
+            const int32_t v = (s2 < symbol_len) ? (int32_t)norm[s2] : 0;
+            uint32_t tot;
+            const uint32_t ex = tp_block_excl((v > 0 ? (uint32_t)v : 0u) | ((v == -1 ? 1u : 0u) << 20), s_tmp, &tot);
+            if (s2 < symbol_len) first_visit[s2] = (IdxT)(v == -1 ? carry_low + (ex >> 20) : carry_pos + (ex & 0xFFFFF));
+            carry_pos += tot & 0xFFFFF; carry_low += tot >> 20;
+        }
+        __syncthreads();
+        if (carry_pos + carry_low != size) { if (tid == 0) u.status = MICD_ERR_INTERNAL; return; }
+        for (uint32_t s2 = tid; s2 < symbol_len; s2 += TP_THREADS) {
+            const int32_t v = (int32_t)norm[s2];
+            if (v == 0) continue;
+            const uint32_t freq = v > 0 ? (uint32_t)v : 1u;
+            const uint32_t k0 = tl - mic_high_bits(freq);
+            u.tt_nb[s2] = freq | (k0 << 20);
+            u.tt_find[s2] = (int32_t)(v > 0 ? (uint32_t)first_visit[s2] : carry_pos + (uint32_t)first_visit[s2]);
+        }
+        if (tid == 0) u.zero_bits = 0;
+        return;
+    }
     // ---- CTable: stateTable via the parallel spread, symbolTT per symbol ------------------------------
     TpScratch<NormT, IdxT> S;
     S.norm = norm; S.first_visit = first_visit; S.cum_all = cum_all; S.visit_pos = visit_pos;
@@ -272,7 +297,7 @@ __global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
         int rc = MICD_OK;
         uint32_t flavour = 1, count = 0, off = 0, used = 0, symbol_len = 0, tl = 0, small = 0;
         do {
-            if (u.w <= 0 || u.h <= 0 || !u.comp_in) { rc = MICD_ERR_ARGS; break; }
+            if ((u.mode == 0 && (u.w <= 0 || u.h <= 0)) || !u.comp_in) { rc = MICD_ERR_ARGS; break; }
             if (len >= 2 && s_in[0] == 0xFF) {                             // FSEDecompressU16Auto, fse2state.go:102-116
                 if (s_in[1] == 0x84) flavour = 8;
                 else if (s_in[1] == 0x08) flavour = 108;

@@ -247,3 +247,47 @@ def test_strip_sized_unit_matches_oracle(mic, mico, synth, gpu_ready):
     got = mic.compress_single_frame(img, 2577, 256, 4095, 2)
     assert got == want
     assert np.array_equal(mic.decompress_single_frame(got, 2577, 256), img)
+
+
+# ---- bare FSE stage: fse2state_test.go, fse4state_test.go, fse8state_test.go, rans8state_test.go ----
+@pytest.mark.parametrize("flavour", [1, 2, 4, 8, 108])
+def test_fse_stage_matches_oracle(mic, mico, synth, gpu_ready, flavour):
+    img = synth.xr_like(cols=500, rows=180, depth=12, seed=17)
+    tok = mico.delta_rle_compress(img, 4095)
+    rc, want = mico.fse_compress(tok, flavour)
+    assert rc == 0
+    got = mic.fse_compress_u16(tok, flavour)
+    assert got == want
+    if flavour != 1:
+        assert got[:2] == bytes([0xFF, {2: 0x02, 4: 0x04, 8: 0x84, 108: 0x08}[flavour]])   # fse2state_test.go:117-142
+    back = mic.fse_decompress_u16_auto(got, tok.size + 16)
+    assert np.array_equal(back, tok)
+
+
+@pytest.mark.parametrize("flavour", [1, 2, 4, 8, 108])
+def test_fse_stage_edge_cases(mic, mico, gpu_ready, flavour):
+    """all-same -> ErrUseRLE; two elements -> error; lengths n%4, n%8 != 0 with i%8 / i%17 data
+    (fse2state_test.go:178-257, fse4state_test.go:105-, fse8state_test.go:106-, rans8state_test.go:105-147)."""
+    with pytest.raises(mic.ErrUseRLE):
+        mic.fse_compress_u16(np.full(1000, 42, dtype=np.uint16), flavour)
+    with pytest.raises(mic.MicError):
+        mic.fse_compress_u16(np.array([1, 2], dtype=np.uint16), flavour)
+    for n in list(range(9, 16)) + list(range(101, 108)) + list(range(1001, 1008)) + [4096, 70001]:
+        for mod in (8, 17):
+            data = (np.arange(n) % mod).astype(np.uint16)
+            rc, want = mico.fse_compress(data, flavour)
+            if rc != 0:
+                with pytest.raises(mic.MicError) as e:
+                    mic.fse_compress_u16(data, flavour)
+                assert e.value.code == rc, (n, mod)
+                continue
+            got = mic.fse_compress_u16(data, flavour)
+            assert got == want, (n, mod)
+            assert np.array_equal(mic.fse_decompress_u16_auto(got, n + 8), data)
+
+
+def test_fse_stage_incompressible_noise(mic, synth, gpu_ready):
+    noise = (synth.hash_u64(1 << 21, 9) & np.uint64(0xFFFF)).astype(np.uint16)
+    for flavour in (2, 108):
+        with pytest.raises(mic.ErrIncompressible):
+            mic.fse_compress_u16(noise, flavour)
