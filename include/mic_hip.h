@@ -137,6 +137,27 @@ int mic_hip_mic2_info(const uint8_t *compressed, size_t compressed_len,
 int mic_hip_mic2_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *frames_out, size_t frames_cap_px);
 
+/* ---- MIC3 container: tiled RGB whole-slide images ---------------------------------------------- */
+/* Replaces CompressWSI (wsicompress.go:27) + WriteMIC3 (wsiformat.go:99) for 8-bit RGB with the
+ * YCoCg-R colour transform (forced on for RGB, wsiformat.go:93-95).  tile_w / tile_h = 0 select the
+ * 256 x 256 default, levels <= 0 the automatic pyramid depth (wsiformat.go:273-285).  The pyramid
+ * (2x2 box, wsipyramid.go:10-32), tile extraction, colour transform, plane statistics and every
+ * plane's CompressSingleFrame run on the device; the host writes the container. */
+int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
+                         uint8_t *out, size_t out_cap, size_t *out_len);
+/* ReadWSIHeader (wsicompress.go:299). */
+int mic_hip_wsi_info(const uint8_t *compressed, size_t compressed_len, int *width, int *height,
+                     int *tile_w, int *tile_h, int *levels, uint64_t *total_tiles);
+int mic_hip_wsi_level_info(const uint8_t *compressed, size_t compressed_len, int level,
+                           int *width, int *height, int *tiles_x, int *tiles_y);
+/* Replaces DecompressWSITile (wsicompress.go:175): one tile, cropped at the level's edge;
+ * *out_w x *out_h x 3 bytes are written. */
+int mic_hip_wsi_decompress_tile(const uint8_t *compressed, size_t compressed_len, int level, int tile_x, int tile_y,
+                                uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h);
+/* All tiles of one pyramid level in a single batch, stitched into a level-sized RGB image. */
+int mic_hip_wsi_decompress_level(const uint8_t *compressed, size_t compressed_len, int level,
+                                 uint8_t *rgb_out, size_t out_cap);
+
 /* ---- device-resident sessions (inputs and outputs stay in HBM) ------------------------------ */
 /* A session owns the workspace for up to max_units units of up to max_px pixels each and
  * runs the same kernels as the calls above on data that is already on the device.  This is

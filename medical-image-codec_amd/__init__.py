@@ -87,6 +87,8 @@ ABI_SYMBOLS = [
     "mic_hip_compress_batch", "mic_hip_decompress_batch",
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
     "mic_hip_mic2_compress", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
+    "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
+    "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level",
     "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
     "mic_hip_session_encode", "mic_hip_session_decode",
     "mic_hip_session_encode_enqueue", "mic_hip_session_encode_finish",
@@ -128,6 +130,11 @@ def lib() -> C.CDLL:
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_mic2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_wsi_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.c_uint64)]
+    L.mic_hip_wsi_level_info.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.POINTER(C.c_int)] * 4
+    L.mic_hip_wsi_decompress_tile.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mic_hip_wsi_decompress_level.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
     L.mic_hip_session_encode_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Unit), C.c_int]
     L.mic_hip_session_encode_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -299,6 +306,63 @@ def decompress_multi_frame(compressed) -> np.ndarray:
     if rc:
         _raise(rc, "decompress_multi_frame")
     return out.reshape(n.value, h.value, w.value)
+
+
+# ------------------------------------------------------------------ MIC3 / WSI
+def compress_wsi(pixels, width: int, height: int, channels: int = 3, bits_per_sample: int = 8,
+                 tile_w: int = 0, tile_h: int = 0, levels: int = 0) -> bytes:
+    """CompressWSI (wsicompress.go:27) for 8-bit RGB."""
+    if channels != 3 or bits_per_sample != 8:
+        raise MicError(MIC_ERR_UNSUPPORTED, "compress_wsi: only 8-bit RGB")
+    px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+    if px.size != width * height * 3:
+        raise MicError(MIC_ERR_ARGS, "compress_wsi")
+    cap = px.size * 3 + (1 << 20)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_wsi_compress(px.ctypes.data, width, height, tile_w, tile_h, levels, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_wsi")
+    return out[: n.value].tobytes()
+
+
+def read_wsi_header(compressed):
+    """ReadWSIHeader (wsicompress.go:299): dict with the level table."""
+    c = _bytes_arr(compressed)
+    w, h, tw, th, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    tot = C.c_uint64()
+    rc = lib().mic_hip_wsi_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(tw), C.byref(th), C.byref(nl), C.byref(tot))
+    if rc:
+        _raise(rc, "read_wsi_header")
+    levels = []
+    for i in range(nl.value):
+        lw, lh, tx, ty = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().mic_hip_wsi_level_info(c.ctypes.data, c.size, i, C.byref(lw), C.byref(lh), C.byref(tx), C.byref(ty))
+        levels.append(dict(width=lw.value, height=lh.value, tiles_x=tx.value, tiles_y=ty.value))
+    return dict(width=w.value, height=h.value, tile_width=tw.value, tile_height=th.value, total_tiles=tot.value, levels=levels)
+
+
+def decompress_wsi_tile(compressed, level: int, tile_x: int, tile_y: int) -> np.ndarray:
+    """DecompressWSITile (wsicompress.go:175): cropped (h, w, 3) uint8."""
+    c = _bytes_arr(compressed)
+    hdr = read_wsi_header(c)
+    out = np.empty(hdr["tile_width"] * hdr["tile_height"] * 3, dtype=np.uint8)
+    ow, oh = C.c_int(), C.c_int()
+    rc = lib().mic_hip_wsi_decompress_tile(c.ctypes.data, c.size, level, tile_x, tile_y, out.ctypes.data, out.size, C.byref(ow), C.byref(oh))
+    if rc:
+        _raise(rc, "decompress_wsi_tile")
+    return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()
+
+
+def decompress_wsi_level(compressed, level: int = 0) -> np.ndarray:
+    c = _bytes_arr(compressed)
+    hdr = read_wsi_header(c)
+    lv = hdr["levels"][level]
+    out = np.empty(lv["width"] * lv["height"] * 3, dtype=np.uint8)
+    rc = lib().mic_hip_wsi_decompress_level(c.ctypes.data, c.size, level, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "decompress_wsi_level")
+    return out.reshape(lv["height"], lv["width"], 3)
 
 
 # ------------------------------------------------------------------ device-resident sessions

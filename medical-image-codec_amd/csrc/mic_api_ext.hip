@@ -1,0 +1,394 @@
+// mic_api_ext.hip -- MIC3 / WSI on the GPU (wsicompress.go, wsiformat.go, wsipyramid.go, ycocgr.go).
+//
+// CompressWSI = pyramid (2x2 box) -> zero-padded tiles -> YCoCg-R -> three planes per tile ->
+// per plane: constant-zero / constant / CompressSingleFrame / raw fallback -> tile blobs -> MIC3.
+// On the device: the pyramid, the tile extraction fused with the colour transform and the
+// per-plane min/max (which decides the plane mode and the maxValue handed to the unit codec),
+// and the unit codec itself over every non-constant plane of the slide in one batch.  The host
+// writes the container around the plane blobs.  Decode mirrors it: one batch over the planes of
+// the requested tiles, then inverse transform + crop on the device.
+#include "mic_session.h"
+
+namespace {
+
+void put_u32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+void put_u64(uint8_t *p, uint64_t v) { put_u32(p, (uint32_t)v); put_u32(p + 4, (uint32_t)(v >> 32)); }
+uint64_t get_u64(const uint8_t *p) { return (uint64_t)get_u32(p) | ((uint64_t)get_u32(p + 4) << 32); }
+
+// Downsample2xRGB (wsipyramid.go:10-32): (v00+v10+v01+v11+2)/4 per channel, odd edge dropped.
+__global__ void __launch_bounds__(256) k_wsi_downsample(const uint8_t *src, int sw, uint8_t *dst, int dw, int dh) {
+    const size_t n = (size_t)dw * dh * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3); const size_t px = i / 3;
+        const int x = (int)(px % dw), y = (int)(px / dw);
+        const size_t a = ((size_t)(2 * y) * sw + 2 * x) * 3 + c, b = a + 3, d = a + (size_t)sw * 3, e = d + 3;
+        dst[i] = (uint8_t)(((int)src[a] + src[b] + src[d] + src[e] + 2) / 4);
+    }
+}
+
+// extractTileRGB (wsicompress.go:529-555) fused with YCoCgRForward (asm_amd64.go:88-104) and the
+// constant / max scan of compressWSIPlane (wsicompress.go:375-385).  grid = (chunks, tiles).
+// planes: [tile][3][tw*th] u16 ; stats: [tile][3] {min, max} as u32 pairs (pre-set to 0xFFFFFFFF / 0).
+__global__ void __launch_bounds__(256) k_wsi_tile_planes(const uint8_t *img, int iw, int ih, int tw, int th, int tiles_x,
+                                                       int tile_base, uint16_t *planes, uint32_t *stats) {
+    const int tile = blockIdx.y;                                  // slab-local index into planes / stats
+    const int tx = (tile + tile_base) % tiles_x, ty = (tile + tile_base) / tiles_x;
+    const size_t npx = (size_t)tw * th;
+    uint16_t *py = planes + (size_t)tile * 3 * npx, *pco = py + npx, *pcg = pco + npx;
+    uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0, 0, 0 };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % tw), y = (int)(i / tw);
+        const int sx = tx * tw + x, sy = ty * th + y;
+        int r = 0, g = 0, b = 0;
+        if (sx < iw && sy < ih) { const uint8_t *p = img + ((size_t)sy * iw + sx) * 3; r = p[0]; g = p[1]; b = p[2]; }
+        const int co = r - b;
+        const int t = b + (co >> 1);
+        const int cg = g - t;
+        const int yv = t + (cg >> 1);
+        const uint32_t v0 = (uint16_t)yv;
+        const uint32_t v1 = (uint16_t)(((int16_t)co << 1) ^ ((int16_t)co >> 15));     // ZigZag, deltazigzagcompressu16.go:108-111
+        const uint32_t v2 = (uint16_t)(((int16_t)cg << 1) ^ ((int16_t)cg >> 15));
+        py[i] = (uint16_t)v0; pco[i] = (uint16_t)v1; pcg[i] = (uint16_t)v2;
+        mn[0] = min(mn[0], v0); mx[0] = max(mx[0], v0);
+        mn[1] = min(mn[1], v1); mx[1] = max(mx[1], v1);
+        mn[2] = min(mn[2], v2); mx[2] = max(mx[2], v2);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn[k] = min(mn[k], (uint32_t)__shfl_xor((int)mn[k], d)); mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], d)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&stats[((size_t)tile * 3 + k) * 2], mn[k]); atomicMax(&stats[((size_t)tile * 3 + k) * 2 + 1], mx[k]); }
+    }
+}
+
+// YCoCgRInverse (asm_amd64.go:106-121) + cropTile (wsicompress.go:557-570): planes of tile `t` -> dst
+// image region.  grid = (chunks, tiles).  place[t] = {dst x0, dst y0, crop w, crop h}.
+__global__ void __launch_bounds__(256) k_wsi_planes_to_rgb(const uint16_t *planes, int tw, int th, const int4 *place,
+                                                         uint8_t *dst, int dst_w) {
+    const int tile = blockIdx.y;
+    const int4 pl = place[tile];
+    const size_t npx = (size_t)tw * th;
+    const uint16_t *py = planes + (size_t)tile * 3 * npx, *pco = py + npx, *pcg = pco + npx;
+    const size_t n = (size_t)pl.z * pl.w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % pl.z), y = (int)(i / pl.z);
+        const size_t si = (size_t)y * tw + x;
+        const int yv = py[si];
+        const uint32_t uco = pco[si], ucg = pcg[si];
+        const int co = (int)(int16_t)((uco >> 1) ^ (uint16_t)(-(int)(uco & 1)));       // UnZigZag, :113-116
+        const int cg = (int)(int16_t)((ucg >> 1) ^ (uint16_t)(-(int)(ucg & 1)));
+        const int t = yv - (cg >> 1);
+        const int g = cg + t;
+        const int b = t - (co >> 1);
+        const int r = co + b;
+        uint8_t *o = dst + ((size_t)(pl.y + y) * dst_w + (pl.x + x)) * 3;
+        o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill_u16(uint16_t *p, size_t n, uint16_t v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct Level { int w, h, tx, ty, first; };
+
+// autoLevelCount + computeLevels (wsiformat.go:244-285) with the truncation of wsicompress.go:47-77
+std::vector<Level> plan_levels(int w, int h, int tw, int th, int req) {
+    int n = req;
+    if (n <= 0) { n = 1; int ww = w, hh = h; while (ww > tw || hh > th) { ww /= 2; hh /= 2; n++; if (ww <= 1 && hh <= 1) break; } }
+    std::vector<Level> lv;
+    int ww = w, hh = h;
+    for (int i = 0; i < n; i++) {
+        if (i > 0) { const int nw = lv[i - 1].w / 2, nh = lv[i - 1].h / 2; if (nw == 0 || nh == 0) break; ww = nw; hh = nh; }
+        lv.push_back(Level{ ww, hh, (ww + tw - 1) / tw, (hh + th - 1) / th, 0 });
+    }
+    int idx = 0;
+    for (auto &l : lv) { l.first = idx; idx += l.tx * l.ty; }
+    return lv;
+}
+
+struct Mic3 {
+    int w, h, tw, th, channels, bps, flags, nlev; uint64_t total; size_t data_off;
+    std::vector<Level> lv;
+};
+int parse_mic3(const uint8_t *c, size_t len, Mic3 &m) {                       // ReadMIC3Header, wsiformat.go:169-227
+    if (len < 48 || memcmp(c, "MIC3", 4) != 0) return MIC_ERR_CORRUPT;
+    if (get_u32(c + 4) != 1) return MIC_ERR_CORRUPT;
+    m.w = (int)get_u32(c + 8); m.h = (int)get_u32(c + 12); m.tw = (int)get_u32(c + 16); m.th = (int)get_u32(c + 20);
+    m.channels = c[24] | (c[25] << 8); m.bps = c[26]; m.flags = c[27]; m.nlev = c[28] | (c[29] << 8); m.total = get_u64(c + 32);
+    if (len < 48 + 20 * (size_t)m.nlev) return MIC_ERR_CORRUPT;
+    if (m.total > (len - 48 - 20 * (size_t)m.nlev) / 16) return MIC_ERR_CORRUPT;
+    m.lv.clear();
+    for (int i = 0; i < m.nlev; i++) {
+        const uint8_t *p = c + 48 + 20 * (size_t)i;
+        m.lv.push_back(Level{ (int)get_u32(p), (int)get_u32(p + 4), (int)get_u32(p + 8), (int)get_u32(p + 12), (int)get_u32(p + 16) });
+    }
+    m.data_off = 48 + 20 * (size_t)m.nlev + 16 * (size_t)m.total;
+    if (m.tw <= 0 || m.th <= 0 || (size_t)m.tw * m.th > ((size_t)1 << 26)) return MIC_ERR_CORRUPT;
+    return MIC_OK;
+}
+
+// decode the given tiles (global indices) of one level into dst (an image of dst_w x dst_h RGB);
+// place[k] = where tile k goes and how much of it is kept
+int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<size_t> &tiles, const std::vector<int4> &place,
+                 uint8_t *rgb_out, int dst_w, int dst_h) {
+    if (m.channels != 3 || m.bps != 8 || !(m.flags & 0x02)) return MIC_ERR_UNSUPPORTED;
+    mic_hip_session *s = &g_default;
+    const size_t npx = (size_t)m.tw * m.th;
+    const size_t ntile = tiles.size();
+    // per-tile chunking keeps the unit workspace bounded
+    const size_t per = std::max<size_t>(1, kWorkspaceBudget / (3 * unit_ws_bytes(npx)));
+    DevBuf planes, d_place, d_out;
+    int rc;
+    if ((rc = d_out.reserve((size_t)dst_w * dst_h * 3 + 64))) return rc;
+    for (size_t t0 = 0; t0 < ntile && rc == MIC_OK; t0 += per) {
+        const size_t nt = std::min(per, ntile - t0);
+        if ((rc = planes.reserve(nt * 3 * npx * 2 + 64))) break;
+        if ((rc = d_place.reserve(nt * sizeof(int4) + 64))) break;
+        if ((rc = s->ensure(1, npx))) break;
+        std::vector<mic_hip_unit> units; std::vector<uint64_t> offs(1, 0); std::vector<uint8_t> comp;
+        struct Fill { size_t plane; int mode; uint16_t val; const uint8_t *raw; };
+        std::vector<Fill> fills;
+        for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
+            const size_t gi = tiles[t0 + k];
+            if (gi >= m.total) { rc = MIC_ERR_CORRUPT; break; }
+            const uint8_t *e = c + 48 + 20 * (size_t)m.nlev + 16 * gi;
+            const uint64_t bo = get_u64(e), bl = get_u64(e + 8);
+            if (m.data_off + bo + bl > len || bl < 12) { rc = MIC_ERR_CORRUPT; break; }   // ExtractTileBlob, wsiformat.go:230-241
+            const uint8_t *blob = c + m.data_off + bo;
+            const size_t l0 = get_u32(blob), l1 = get_u32(blob + 4), l2 = get_u32(blob + 8);
+            if (12 + l0 + l1 + l2 > bl) { rc = MIC_ERR_CORRUPT; break; }                   // wsicompress.go:440-442
+            const size_t pl_off[3] = { 12, 12 + l0, 12 + l0 + l1 }, pl_len[3] = { l0, l1, l2 };
+            for (int p = 0; p < 3; p++) {                                                  // decompressWSIPlane, :464-500
+                const uint8_t *d = blob + pl_off[p]; const size_t dl = pl_len[p];
+                const size_t plane = k * 3 + (size_t)p;
+                if (dl == 0) { rc = MIC_ERR_CORRUPT; break; }
+                if (d[0] == 0) fills.push_back(Fill{ plane, 0, 0, nullptr });
+                else if (d[0] == 1) { if (dl < 3) { rc = MIC_ERR_CORRUPT; break; } fills.push_back(Fill{ plane, 1, (uint16_t)(d[1] | (d[2] << 8)), nullptr }); }
+                else if (d[0] == 2) {
+                    units.push_back(mic_hip_unit{ plane * npx, m.tw, m.th, 0, 0 });
+                    comp.insert(comp.end(), d + 1, d + dl);
+                    offs.push_back(comp.size());
+                } else if (d[0] == 3) { if (dl < 1 + 2 * npx) { rc = MIC_ERR_CORRUPT; break; } fills.push_back(Fill{ plane, 3, 0, d + 1 }); }
+                else { rc = MIC_ERR_CORRUPT; break; }
+            }
+        }
+        if (rc) break;
+        uint16_t *dp = (uint16_t *)planes.p;
+        for (const Fill &f : fills) {
+            if (f.mode == 3) HIP_TRY(hipMemcpyAsync(dp + f.plane * npx, f.raw, npx * 2, hipMemcpyHostToDevice, s->stream));
+            else hipLaunchKernelGGL(k_fill_u16, dim3(64), dim3(256), 0, s->stream, dp + f.plane * npx, npx, f.val);
+        }
+        if (!units.empty()) {
+            if ((rc = s->io_comp.reserve(comp.size() + 64))) break;
+            HIP_TRY(hipMemcpyAsync(s->io_comp.p, comp.data(), comp.size(), hipMemcpyHostToDevice, s->stream));
+            if ((rc = session_decode_enqueue(s, (const uint8_t *)s->io_comp.p, offs.data(), units.data(), (int)units.size(), dp))) break;
+            std::vector<int32_t> st(units.size());
+            if ((rc = session_decode_finish(s, st.data()))) break;
+            for (int32_t v : st) if (v != MIC_OK) { rc = v; break; }
+            if (rc) break;
+        }
+        HIP_TRY(hipMemcpyAsync(d_place.p, place.data() + t0, nt * sizeof(int4), hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_wsi_planes_to_rgb, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place.p,
+                           (uint8_t *)d_out.p, dst_w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    if (rc == MIC_OK) {
+        hipError_t e = hipMemcpy(rgb_out, d_out.p, (size_t)dst_w * dst_h * 3, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = MIC_ERR_DEVICE;
+    }
+    planes.release(); d_place.release(); d_out.release();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// CompressWSI for 8-bit RGB (wsicompress.go:27-171)
+int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
+                         uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!rgb || !out || !out_len || width <= 0 || height <= 0 || tile_w < 0 || tile_h < 0) return MIC_ERR_ARGS;
+    if (tile_w == 0) tile_w = 256;                                                          // WSIOptions.defaults, wsiformat.go:86-96
+    if (tile_h == 0) tile_h = 256;
+    if ((size_t)tile_w * tile_h > ((size_t)1 << 26) || levels > 32) return MIC_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if ((rc = s->ensure(1, (size_t)tile_w * tile_h))) return rc;
+    const std::vector<Level> lv = plan_levels(width, height, tile_w, tile_h, levels);
+    const int nlev = (int)lv.size();
+    size_t total_tiles = 0;
+    for (const Level &l : lv) total_tiles += (size_t)l.tx * l.ty;
+    const size_t hdr = 48 + 20 * (size_t)nlev + 16 * total_tiles;
+    if (out_cap < hdr) return MIC_ERR_CAPACITY;
+    const size_t npx = (size_t)tile_w * tile_h;
+    // pyramid on the device
+    std::vector<DevBuf> img((size_t)nlev);
+    DevBuf planes, stats;
+    auto cleanup = [&]() { for (auto &b : img) b.release(); planes.release(); stats.release(); };
+    if ((rc = img[0].reserve((size_t)width * height * 3 + 64))) { cleanup(); return rc; }
+    if (hipMemcpyAsync(img[0].p, rgb, (size_t)width * height * 3, hipMemcpyHostToDevice, s->stream) != hipSuccess) { cleanup(); return MIC_ERR_DEVICE; }
+    for (int i = 1; i < nlev; i++) {
+        if ((rc = img[(size_t)i].reserve((size_t)lv[i].w * lv[i].h * 3 + 64))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(k_wsi_downsample, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)i - 1].p, lv[i - 1].w,
+                           (uint8_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
+    }
+    // tiles are processed in slabs that keep planes + unit workspace bounded
+    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (3 * unit_ws_bytes(npx)), ((size_t)8 << 30) / (3 * npx * 2)));
+    std::vector<std::vector<uint8_t>> tile_blobs(total_tiles);
+    for (int li = 0; li < nlev && rc == MIC_OK; li++) {
+        const Level &L = lv[(size_t)li];
+        const size_t ntl = (size_t)L.tx * L.ty;
+        for (size_t t0 = 0; t0 < ntl && rc == MIC_OK; t0 += per) {
+            const size_t nt = std::min(per, ntl - t0);
+            if ((rc = planes.reserve(nt * 3 * npx * 2 + 64))) break;
+            if ((rc = stats.reserve(nt * 3 * 8 + 64))) break;
+            std::vector<uint32_t> st(nt * 6);
+            for (size_t k = 0; k < nt * 3; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
+            if (hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+            hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p, L.w, L.h,
+                               tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+            if (hipGetLastError() != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+            if (hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+            if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+            // plane modes (compressWSIPlane, wsicompress.go:373-421)
+            std::vector<mic_hip_unit> units; std::vector<size_t> unit_plane;
+            for (size_t p = 0; p < nt * 3; p++) {
+                const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
+                if (mn == mx) continue;                                                    // constant plane
+                units.push_back(mic_hip_unit{ p * npx, tile_w, tile_h, (uint16_t)std::max<uint32_t>(mx, 255u), 2 });   // :398-402
+                unit_plane.push_back(p);
+            }
+            std::vector<uint64_t> offs(units.size() + 1, 0); std::vector<int32_t> ust(units.size()), uns(units.size());
+            std::vector<uint8_t> packed;
+            if (!units.empty()) {
+                if ((rc = session_encode_enqueue(s, (const uint16_t *)planes.p, units.data(), (int)units.size()))) break;
+                const uint8_t *d_blobs = nullptr;
+                if ((rc = session_encode_finish(s, &d_blobs, offs.data(), ust.data(), uns.data()))) break;
+                packed.resize((size_t)offs.back() + 16);
+                if (offs.back() && hipMemcpy(packed.data(), d_blobs, (size_t)offs.back(), hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+            }
+            std::vector<long> unit_of(nt * 3, -1);
+            for (size_t k = 0; k < units.size(); k++) unit_of[unit_plane[k]] = (long)k;
+            std::vector<uint16_t> rawbuf;
+            for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
+                std::vector<uint8_t> &tb = tile_blobs[(size_t)L.first + t0 + k];
+                tb.assign(12, 0);
+                for (int p = 0; p < 3; p++) {
+                    const size_t pi = k * 3 + (size_t)p;
+                    const size_t before = tb.size();
+                    const uint32_t mn = st[2 * pi], mx = st[2 * pi + 1];
+                    if (mn == mx) {
+                        if (mn == 0) tb.push_back(0);                                      // planeConstantZero
+                        else { tb.push_back(1); tb.push_back((uint8_t)mn); tb.push_back((uint8_t)(mn >> 8)); }
+                    } else {
+                        const long ui = unit_of[pi];
+                        const int32_t ustat = ust[(size_t)ui];
+                        if (ustat == MIC_OK) {
+                            tb.push_back(2);
+                            tb.insert(tb.end(), packed.begin() + (long)offs[(size_t)ui], packed.begin() + (long)offs[(size_t)ui + 1]);
+                        } else if (ustat == MIC_ERR_USE_RLE || ustat == MIC_ERR_INCOMPRESSIBLE) {      // raw fallback, :403-414
+                            rawbuf.resize(npx);
+                            if (hipMemcpy(rawbuf.data(), (uint16_t *)planes.p + pi * npx, npx * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+                            tb.push_back(3);
+                            const uint8_t *rb = (const uint8_t *)rawbuf.data();
+                            tb.insert(tb.end(), rb, rb + npx * 2);
+                        } else { rc = ustat; break; }
+                    }
+                    put_u32(tb.data() + 4 * p, (uint32_t)(tb.size() - before));
+                }
+            }
+        }
+    }
+    cleanup();
+    if (rc) return rc;
+    size_t total = 0;
+    for (const auto &tb : tile_blobs) total += tb.size();
+    if (out_cap < hdr + total) return MIC_ERR_CAPACITY;
+    memset(out, 0, hdr);                                                                    // WriteMIC3, wsiformat.go:99-165
+    memcpy(out, "MIC3", 4); put_u32(out + 4, 1); put_u32(out + 8, (uint32_t)width); put_u32(out + 12, (uint32_t)height);
+    put_u32(out + 16, (uint32_t)tile_w); put_u32(out + 20, (uint32_t)tile_h);
+    out[24] = 3; out[25] = 0; out[26] = 8; out[27] = 0x01 | 0x02;
+    out[28] = (uint8_t)nlev; out[29] = (uint8_t)(nlev >> 8);
+    put_u64(out + 32, (uint64_t)total_tiles);
+    for (int i = 0; i < nlev; i++) {
+        uint8_t *ld = out + 48 + 20 * (size_t)i;
+        put_u32(ld, (uint32_t)lv[(size_t)i].w); put_u32(ld + 4, (uint32_t)lv[(size_t)i].h); put_u32(ld + 8, (uint32_t)lv[(size_t)i].tx);
+        put_u32(ld + 12, (uint32_t)lv[(size_t)i].ty); put_u32(ld + 16, (uint32_t)lv[(size_t)i].first);
+    }
+    size_t off = 0;
+    for (size_t t = 0; t < total_tiles; t++) {
+        uint8_t *e = out + 48 + 20 * (size_t)nlev + 16 * t;
+        put_u64(e, (uint64_t)off); put_u64(e + 8, (uint64_t)tile_blobs[t].size());
+        memcpy(out + hdr + off, tile_blobs[t].data(), tile_blobs[t].size());
+        off += tile_blobs[t].size();
+    }
+    *out_len = hdr + total;
+    return MIC_OK;
+}
+
+// ReadWSIHeader (wsicompress.go:299-306)
+int mic_hip_wsi_info(const uint8_t *c, size_t len, int *width, int *height, int *tile_w, int *tile_h, int *levels, uint64_t *total_tiles) {
+    if (!c) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (width) *width = m.w; if (height) *height = m.h; if (tile_w) *tile_w = m.tw; if (tile_h) *tile_h = m.th;
+    if (levels) *levels = m.nlev; if (total_tiles) *total_tiles = m.total;
+    return MIC_OK;
+}
+int mic_hip_wsi_level_info(const uint8_t *c, size_t len, int level, int *width, int *height, int *tiles_x, int *tiles_y) {
+    if (!c) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (level < 0 || level >= m.nlev) return MIC_ERR_ARGS;
+    const Level &L = m.lv[(size_t)level];
+    if (width) *width = L.w; if (height) *height = L.h; if (tiles_x) *tiles_x = L.tx; if (tiles_y) *tiles_y = L.ty;
+    return MIC_OK;
+}
+
+// DecompressWSITile (wsicompress.go:175-217): one tile, cropped at the level's edge
+int mic_hip_wsi_decompress_tile(const uint8_t *c, size_t len, int level, int tile_x, int tile_y,
+                                uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) {
+    if (!c || !rgb_out) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (level < 0 || level >= m.nlev) return MIC_ERR_ARGS;
+    const Level &L = m.lv[(size_t)level];
+    if (tile_x < 0 || tile_x >= L.tx || tile_y < 0 || tile_y >= L.ty) return MIC_ERR_ARGS;
+    const int aw = std::min(m.tw, L.w - tile_x * m.tw), ah = std::min(m.th, L.h - tile_y * m.th);
+    if (aw <= 0 || ah <= 0) return MIC_ERR_CORRUPT;
+    if ((size_t)aw * ah * 3 > out_cap) return MIC_ERR_CAPACITY;
+    if (out_w) *out_w = aw; if (out_h) *out_h = ah;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((rc = ensure_device())) return rc;
+    std::vector<size_t> tiles(1, (size_t)L.first + (size_t)tile_y * L.tx + tile_x);
+    std::vector<int4> place(1, make_int4(0, 0, aw, ah));
+    return decode_tiles(c, len, m, tiles, place, rgb_out, aw, ah);
+}
+
+// Whole pyramid level in one batch: every tile of the level, stitched (viewer / bench path)
+int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_t *rgb_out, size_t out_cap) {
+    if (!c || !rgb_out) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (level < 0 || level >= m.nlev) return MIC_ERR_ARGS;
+    const Level &L = m.lv[(size_t)level];
+    if (L.w <= 0 || L.h <= 0 || (size_t)L.w * L.h * 3 > out_cap) return (L.w <= 0 || L.h <= 0) ? MIC_ERR_CORRUPT : MIC_ERR_CAPACITY;
+    if ((size_t)L.tx * m.tw < (size_t)L.w || (size_t)L.ty * m.th < (size_t)L.h) return MIC_ERR_CORRUPT;
+    std::vector<size_t> tiles; std::vector<int4> place;
+    for (int ty = 0; ty < L.ty; ty++) for (int tx = 0; tx < L.tx; tx++) {
+        const int aw = std::min(m.tw, L.w - tx * m.tw), ah = std::min(m.th, L.h - ty * m.th);
+        if (aw <= 0 || ah <= 0) continue;
+        tiles.push_back((size_t)L.first + (size_t)ty * L.tx + tx);
+        place.push_back(make_int4(tx * m.tw, ty * m.th, aw, ah));
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((rc = ensure_device())) return rc;
+    return decode_tiles(c, len, m, tiles, place, rgb_out, L.w, L.h);
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// mic_session.h -- host-side session state shared by mic_api.hip and mic_api_ext.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mic_hip.h"
+#include "mic_dev.h"
+#include "mic_launch.h"
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            if (getenv("MIC_HIP_DEBUG"))                                                  \
+                fprintf(stderr, "mic_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? MIC_ERR_NOMEM : MIC_ERR_DEVICE;            \
+        }                                                                                 \
+    } while (0)
+
+namespace micapi {
+
+extern std::mutex g_mu;     // serialises the default session (entry points are re-entrant)
+extern int g_device;
+extern bool g_device_ok;
+extern std::string g_device_name;
+int ensure_device();
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return MIC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return MIC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr size_t kSym = 65536;
+
+inline size_t tok_cap_for(size_t px) { return 4 * px + 16; }
+inline size_t blob_cap_for(size_t px) { return 8 + 131080 + 2 * tok_cap_for(px) + 16; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace micapi
+using namespace micapi;
+
+struct mic_hip_session {
+    int max_units = 0; size_t max_px = 0;
+    hipStream_t stream = nullptr;
+    DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
+    DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
+    std::vector<MicUnit> h_units;
+    std::vector<uint64_t> h_off;
+    int n_last = 0;
+    int variant = 0;                        // kernel generation selector (0 = default)
+    MicTimer timer;
+    std::vector<std::string> t_names; std::vector<float> t_ms;
+    size_t tok_stride = 0, blob_stride = 0, seg_stride = 0, sym_stride = 0, flag_stride = 0;
+
+    int ensure(int n, size_t px) {
+        if (!stream) HIP_TRY(hipStreamCreate(&stream));
+        if (n <= max_units && px <= max_px) return MIC_OK;
+        int nn = std::max(n, max_units); size_t pp = std::max(px, max_px);
+        tok_stride = align_up(tok_cap_for(pp) * 2, 256);
+        blob_stride = align_up(blob_cap_for(pp), 256);
+        seg_stride = align_up((2 * pp + 8) * 8, 256);
+        sym_stride = align_up(tok_cap_for(pp) * 2, 256);
+        flag_stride = align_up(pp / 8 + 8, 256);
+        int rc;
+        if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
+        if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
+        if ((rc = hist.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = norm.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_nb.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_find.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = state_tab.reserve(kSym * 4 * (size_t)nn))) return rc;
+        if ((rc = tab_sym.reserve(kSym * 2 * (size_t)nn))) return rc;
+        if ((rc = cumul.reserve((kSym + 64) * 4 * (size_t)nn))) return rc;
+        if ((rc = blob.reserve(blob_stride * (size_t)nn))) return rc;
+        if ((rc = offsets.reserve(8 * ((size_t)nn + 1)))) return rc;
+        if ((rc = seg.reserve(seg_stride * (size_t)nn))) return rc;
+        if ((rc = sym.reserve(sym_stride * (size_t)nn))) return rc;
+        if ((rc = flags.reserve(flag_stride * (size_t)nn))) return rc;
+        max_units = nn; max_px = pp;
+        return MIC_OK;
+    }
+    void fill_workspace(MicUnit &u, int i) {
+        u.tok = (uint16_t *)((char *)tok.p + tok_stride * (size_t)i);
+        u.tok_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
+        u.hist = (uint32_t *)hist.p + kSym * (size_t)i;
+        u.norm = (int32_t *)norm.p + kSym * (size_t)i;
+        u.tt_nb = (uint32_t *)tt_nb.p + kSym * (size_t)i;
+        u.tt_find = (int32_t *)tt_find.p + kSym * (size_t)i;
+        u.state_tab = (uint32_t *)state_tab.p + kSym * (size_t)i;
+        u.tab_sym = (uint16_t *)tab_sym.p + kSym * (size_t)i;
+        u.cumul = (int32_t *)cumul.p + (kSym + 64) * (size_t)i;
+        u.blob = (uint8_t *)blob.p + blob_stride * (size_t)i;
+        u.blob_cap = (uint32_t)std::min<size_t>(blob_cap_for(max_px), 0xFFFFFFF0u);
+        u.seg = (uint2 *)((char *)seg.p + seg_stride * (size_t)i);
+        u.seg_cap = (uint32_t)std::min<size_t>(2 * max_px + 8, 0xFFFFFFF0u);
+        u.sym = (uint16_t *)((char *)sym.p + sym_stride * (size_t)i);
+        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
+        u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
+    }
+    void release() {
+        DevBuf *all[] = { &units, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp };
+        for (DevBuf *b : all) b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        timer.destroy();
+    }
+};
+
+
+namespace micapi {
+extern mic_hip_session g_default;   // guarded by g_mu
+int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n);
+int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates);
+int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
+                           const mic_hip_unit *units, int n, uint16_t *d_pixels_out);
+int session_decode_finish(mic_hip_session *s, int32_t *h_status);
+size_t unit_ws_bytes(size_t px);
+constexpr size_t kWorkspaceBudget = (size_t)24 << 30;
+}  // namespace micapi

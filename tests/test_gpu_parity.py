@@ -291,3 +291,53 @@ def test_fse_stage_incompressible_noise(mic, synth, gpu_ready):
     for flavour in (2, 108):
         with pytest.raises(mic.ErrIncompressible):
             mic.fse_compress_u16(noise, flavour)
+
+
+# ---- MIC3 / WSI: wsi_test.go:361-603 (tile kinds, full slide, odd dimensions) ------------------------
+def test_wsi_matches_oracle_and_round_trips(mic, mico, synth, gpu_ready):
+    img = synth.wsi_like(600, 420, seed=5)                   # 3 levels, edge tiles, white + tissue tiles
+    rc, want = mico.wsi_compress(img)
+    assert rc == 0
+    got = mic.compress_wsi(img, 600, 420)
+    assert got == want
+    hdr = mic.read_wsi_header(got)
+    assert [(l["width"], l["height"]) for l in hdr["levels"]] == [(600, 420), (300, 210), (150, 105)]
+    assert np.array_equal(mic.decompress_wsi_level(got, 0), img)
+    for lvl in range(3):
+        for ty in range(hdr["levels"][lvl]["tiles_y"]):
+            for tx in range(hdr["levels"][lvl]["tiles_x"]):
+                rc, t = mico.wsi_decompress_tile_at(got, lvl, tx, ty)
+                assert rc == 0
+                assert np.array_equal(mic.decompress_wsi_tile(got, lvl, tx, ty), t)
+
+
+def test_wsi_white_slide_is_101_bytes(mic, gpu_ready):
+    white = np.full((256, 256, 3), 255, dtype=np.uint8)
+    blob = mic.compress_wsi(white, 256, 256)
+    assert len(blob) == 101                                  # docs/compression-results.md:167-174 (1946x)
+    assert np.array_equal(mic.decompress_wsi_level(blob, 0), white)
+
+
+def test_wsi_noise_tile_raw_fallback_and_small_tiles(mic, mico, synth, gpu_ready):
+    """Noise planes: ErrIncompressible -> raw plane fallback (wsicompress.go:403-414).  With tiny noisy
+    tiles the reference's normaliser fails outright (oracle: internal error); the GPU must agree."""
+    h = synth.hash_u64(300 * 200 * 3, 77)
+    noise = (h & np.uint64(0xFF)).astype(np.uint8).reshape(200, 300, 3)
+    for tw, th in ((0, 0), (128, 64)):
+        rc, want = mico.wsi_compress(noise, tw or 256, th or 256)
+        if rc != 0:
+            with pytest.raises(mic.MicError) as e:
+                mic.compress_wsi(noise, 300, 200, tile_w=tw, tile_h=th)
+            assert e.value.code == rc
+            continue
+        got = mic.compress_wsi(noise, 300, 200, tile_w=tw, tile_h=th)
+        assert got == want
+        assert np.array_equal(mic.decompress_wsi_level(got, 0), noise)
+    # smooth content with small tiles exercises many tiles per level and cropped edges
+    img = synth.wsi_like(333, 217, seed=8)
+    rc, want = mico.wsi_compress(img, 200, 100)
+    assert rc == 0
+    got = mic.compress_wsi(img, 333, 217, tile_w=200, tile_h=100)
+    assert got == want
+    assert np.array_equal(mic.decompress_wsi_level(got, 0), img)
+    assert np.array_equal(mic.decompress_wsi_level(got, 1), mic.decompress_wsi_level(want, 1))
