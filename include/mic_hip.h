@@ -137,6 +137,19 @@ int mic_hip_mic2_info(const uint8_t *compressed, size_t compressed_len,
 int mic_hip_mic2_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *frames_out, size_t frames_cap_px);
 
+/* ---- WaveletV2 -------------------------------------------------------------------------------- */
+/* Replaces WaveletV2RLEFSECompressU16 and WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303,
+ * :374; identical streams): up to 8 levels of 5/3 integer lifting in Mallat layout, subband scan, zigzag
+ * with 3-word escape, RLE with length prefix, 4-state FSE (no fallback), 11-byte header.
+ * NOTE the argument order of the reference: (pixels, rows, cols, maxValue, levels). */
+int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint16_t max_value, int levels,
+                                uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_wavelet_v2_info(const uint8_t *compressed, size_t compressed_len,
+                            int *rows, int *cols, int *max_value, int *levels);
+/* Replaces WaveletV2RLEFSEDecompressU16 / WaveletV2SIMDRLEFSEDecompressU16 (:380, :493). */
+int mic_hip_wavelet_v2_decompress(const uint8_t *compressed, size_t compressed_len,
+                                  uint16_t *pixels_out, size_t out_cap_px);
+
 /* ---- MIC3 container: tiled RGB whole-slide images ---------------------------------------------- */
 /* Replaces CompressWSI (wsicompress.go:27) + WriteMIC3 (wsiformat.go:99) for 8-bit RGB with the
  * YCoCg-R colour transform (forced on for RGB, wsiformat.go:93-95).  tile_w / tile_h = 0 select the

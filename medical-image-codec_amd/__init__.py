@@ -87,6 +87,7 @@ ABI_SYMBOLS = [
     "mic_hip_compress_batch", "mic_hip_decompress_batch",
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
     "mic_hip_mic2_compress", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
+    "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level",
     "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
@@ -130,6 +131,9 @@ def lib() -> C.CDLL:
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_mic2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.mic_hip_wavelet_v2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
+    L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_wsi_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.c_uint64)]
     L.mic_hip_wsi_level_info.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.POINTER(C.c_int)] * 4
@@ -306,6 +310,35 @@ def decompress_multi_frame(compressed) -> np.ndarray:
     if rc:
         _raise(rc, "decompress_multi_frame")
     return out.reshape(n.value, h.value, w.value)
+
+
+# ------------------------------------------------------------------ WaveletV2
+def wavelet_v2_compress(pixels, rows: int, cols: int, max_value: int, levels: int = 5) -> bytes:
+    """WaveletV2RLEFSECompressU16 / WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303, :374)."""
+    px = _u16(pixels).reshape(-1)
+    if px.size != rows * cols:
+        raise MicError(MIC_ERR_ARGS, "pixel count does not match rows*cols")
+    cap = px.size * 2 + 200000
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_wavelet_v2_compress(px.ctypes.data, rows, cols, max_value, levels, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "wavelet_v2_compress")
+    return out[: n.value].tobytes()
+
+
+def wavelet_v2_decompress(compressed) -> Tuple[np.ndarray, int, int]:
+    """WaveletV2{,SIMD}RLEFSEDecompressU16 (:380, :493): returns (pixels, rows, cols)."""
+    c = _bytes_arr(compressed)
+    r, cc, mv, lv = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_wavelet_v2_info(c.ctypes.data, c.size, C.byref(r), C.byref(cc), C.byref(mv), C.byref(lv))
+    if rc:
+        _raise(rc, "wavelet_v2_decompress")
+    out = np.empty(max(r.value, 0) * max(cc.value, 0), dtype=np.uint16)
+    rc = lib().mic_hip_wavelet_v2_decompress(c.ctypes.data, c.size, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "wavelet_v2_decompress")
+    return out.reshape(r.value, cc.value), r.value, cc.value
 
 
 # ------------------------------------------------------------------ MIC3 / WSI

@@ -150,6 +150,10 @@ __device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t lane) 
     return v;
 }
 
+// SRC 0: frame units (mode 0) -- symbols are the Delta(avg) residuals of the pixels, stream = [delim][RLE(maxValue, symbols)].
+// SRC 1: RLE-of-symbols units (mode 2, wavelet / residual paths) -- RleCompressU16.Init(len,1,max).Compress(symbols)
+//        (rlecompressu16.go:85-93): symbols come from u.sym[0..u.nsym), stream = [max][len>>16][len&0xFFFF][RLE(symbols)].
+template <int SRC>
 __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     __shared__ uint16_t xs[TK_WIN + 16];          // [0..5] = 6 symbols before the tile, [6..] = new symbols
@@ -159,27 +163,28 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (u.mode != 0) return;                                  // bare-FSE units bring their own symbols
+    if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
+    if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
     if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; }
     const int depth = mic_len16(u.max_value);
-    if (u.w <= 0 || u.h <= 0) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
+    if (!SRC && (u.w <= 0 || u.h <= 0)) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
     if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
     const uint32_t thr = (1u << (depth - 1)) - 1;
     const uint32_t delim = (1u << depth) - 1;
     const uint32_t mid = (1u << (depth - 1)) - 1;          // Len16(delim) == depth
     const uint32_t c = mid - 3;
-    const uint16_t *in = u.px_in;
+    const uint16_t *in = SRC ? (const uint16_t *)u.sym : u.px_in;
     uint16_t *tok = u.tok;
     const uint32_t cap = u.tok_cap;
-    const uint32_t W = (uint32_t)u.w;
-    const uint32_t npx = W * (uint32_t)u.h;
+    const uint32_t W = SRC ? 1u : (uint32_t)u.w;
+    const uint32_t npx = SRC ? u.nsym : W * (uint32_t)u.h;
     const uint32_t ntiles = (npx + TK_THREADS * TK_PPT - 1) / (TK_THREADS * TK_PPT);
     // carried, work-group uniform state
-    uint32_t g0 = 1;                 // symbols generated so far; symbol 0 = maxValue is pre-seeded in the halo
-    uint32_t outp = 1;               // tokens written so far; tok[0] = delimiter (rlecompressu16.go:21)
+    uint32_t g0 = SRC ? 0u : 1u;     // symbols generated so far; frames: symbol 0 = maxValue is pre-seeded in the halo
+    uint32_t outp = SRC ? 3u : 1u;   // tokens written so far; tok[0] = delimiter / max (rlecompressu16.go:21) [+ length words]
     uint32_t run1 = 0, str1 = 0;     // index+1 of the first symbol of the current run / diff stretch (0 = none)
     uint32_t last_same = 0;
-    const uint32_t hlo = (delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
+    const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
     uint32_t *ghist = u.hist;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
     __syncthreads();
@@ -187,7 +192,17 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         const uint32_t d = v - hlo;
         if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u); else atomicAdd(&ghist[v], 1u);
     };
-    if (tid == 0) { if (cap > 0) { tok[0] = (uint16_t)delim; count_tok(delim); } xs[5] = u.max_value; }
+    if (tid == 0) {
+        if (SRC) {
+            if (cap > 2) {
+                tok[0] = u.max_value; tok[1] = (uint16_t)(npx >> 16); tok[2] = (uint16_t)npx;   // rlecompressu16.go:21, :86-87
+                count_tok(u.max_value); count_tok(npx >> 16); count_tok(npx & 0xFFFF);
+            } else s_ovf = 1;
+        } else {
+            if (cap > 0) { tok[0] = (uint16_t)delim; count_tok(delim); }
+            xs[5] = u.max_value;
+        }
+    }
     __syncthreads();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
@@ -198,6 +213,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
 #pragma unroll
             for (int k = 0; k < TK_PPT; k++) {
                 const uint32_t g = gbase + k;
+                if (SRC) { if (g < npx) ls[cnt++] = in[g]; continue; }
                 if (g < npx) {
                     const uint32_t y = g / W, x = g - y * W;
                     int32_t prev = 0;
@@ -919,7 +935,8 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         hipLaunchKernelGGL(k_enc_tokens_serial, dim3(n), dim3(64), 0, stream, d_units);
     } else {
         if (t) t->mark("k_enc_tokens_wg");
-        hipLaunchKernelGGL(k_enc_tokens_wg, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tokens_wg<0>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
     }
     if (variant == 100) {
         if (t) t->mark("k_enc_hist");

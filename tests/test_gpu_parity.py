@@ -341,3 +341,44 @@ def test_wsi_noise_tile_raw_fallback_and_small_tiles(mic, mico, synth, gpu_ready
     assert got == want
     assert np.array_equal(mic.decompress_wsi_level(got, 0), img)
     assert np.array_equal(mic.decompress_wsi_level(got, 1), mic.decompress_wsi_level(want, 1))
+
+
+# ---- WaveletV2: waveletu16_test.go:190-248, :385-417; results/.../06-wavelet-simd.txt ---------------------
+@pytest.mark.parametrize("name,ratio", [("MR", 2.381), ("CT", 1.669)])
+def test_wavelet_v2_matches_oracle_on_reference_images(mic, mico, gpu_ready, name, ratio):
+    img = _mr() if name == "MR" else _ct()
+    rows, cols = img.shape
+    rc, want = mico.wavelet_v2_compress(img, int(img.max()), 5)
+    assert rc == 0
+    got = mic.wavelet_v2_compress(img, rows, cols, int(img.max()), 5)
+    assert got == want
+    assert abs(img.size * 2 / len(got) - ratio) < 0.0015        # published WaveletV2 (5 levels) ratio
+    px, r, c = mic.wavelet_v2_decompress(got)
+    assert (r, c) == (rows, cols) and np.array_equal(px, img)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [(63, 65, 5), (130, 70, 8), (214, 176, 5), (256, 256, 1), (301, 97, 3)])
+def test_wavelet_v2_odd_dims_and_levels(mic, mico, synth, gpu_ready, rows, cols, levels):
+    img = synth.xr_like(cols=cols, rows=rows, depth=12, seed=rows * 7 + cols)
+    rc, want = mico.wavelet_v2_compress(img, 4095, levels)
+    if rc != 0:
+        with pytest.raises(mic.MicError) as e:
+            mic.wavelet_v2_compress(img, rows, cols, 4095, levels)
+        assert e.value.code == rc
+        return
+    got = mic.wavelet_v2_compress(img, rows, cols, 4095, levels)
+    assert got == want
+    px, r, c = mic.wavelet_v2_decompress(got)
+    assert (r, c) == (rows, cols) and np.array_equal(px, img)
+
+
+def test_wavelet_v2_escape_path_full_16bit(mic, mico, synth, gpu_ready):
+    """Coefficients beyond +-32767 take the 3-word escape (waveletfsecompressu16.go:33-37)."""
+    img = synth.xr_like(cols=300, rows=200, depth=16, seed=4)
+    img[50:60, 100:140] = 65535; img[60:70, 100:140] = 0
+    rc, want = mico.wavelet_v2_compress(img, 65535, 5)
+    assert rc == 0
+    got = mic.wavelet_v2_compress(img, 200, 300, 65535, 5)
+    assert got == want
+    px, _, _ = mic.wavelet_v2_decompress(got)
+    assert np.array_equal(px, img)
