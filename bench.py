@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "64")), help="frames per GPU per step")
+    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "128")), help="frames per GPU per step")
     ap.add_argument("--strips", type=int, default=8)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--cols", type=int, default=2577)
@@ -170,6 +170,16 @@ def main():
     dom = max(kmean, key=kmean.get)
     alg_bytes = raw_bytes + comp_bytes            # one direction: read raw + write compressed (or the reverse)
     achieved = alg_bytes / (kmean[dom] * 1e-3) / 1e9
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (profiles/, same command); only
+    # quoted when the profile was taken on this very configuration
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        ent = tj.get(dom)
+        if ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
+            traffic = ent["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
 
     ms_step = elapsed / args.steps * 1e3
     value = raw_bytes * world / (elapsed / args.steps) / 1e9
@@ -189,7 +199,7 @@ def main():
         "decode_GBps_kernels": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
         "kernel_ms": {k: round(v, 4) for k, v in kmean.items()},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kmean[dom], 4)},
     }
     if rank == 0 and not args.no_cpu and world == 1:

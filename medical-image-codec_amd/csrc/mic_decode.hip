@@ -234,8 +234,11 @@ __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
 // LDS: chain[2^tl] u32 = newState << 16 | (32-nbBits) << 8 | nbBits ; stage[2][64] u32.
 // ZB = table has 0-bit entries (zeroBits, fsedecompressu16.go:214-216).
 // grid = units, block = 64, dynamic LDS = 4 << tl_hi + 512.
-template <int N, bool ZB>
-__global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
+// TLHI names the table-size class of the launch (tableLog in (TLHI-1 .. TLHI], or <= 13): the classes
+// differ only in dynamic LDS, but distinct instantiations give each its own line in a kernel trace.
+template <int N, bool ZB, int TLHI>
+__global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
+    constexpr uint32_t tl_lo = (TLHI == 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ uint32_t s_mem[];
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK) return;
@@ -371,16 +374,22 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units, uint32_t tl
     }
 }
 
-template <int N, bool ZB>
-static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream) {
+template <int N, bool ZB, int TLHI>
+static void launch_tans_lds_class(MicUnit *d_units, int n, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB, TLHI>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 13) + 512, stream, d_units, 5u, 13u);
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 14) + 512, stream, d_units, 14u, 14u);
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB>), dim3(n), dim3(64), (4u << 15) + 512, stream, d_units, 15u, 15u);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB, TLHI>), dim3(n), dim3(64), (4u << TLHI) + 512, stream, d_units);
+}
+template <int N, bool ZB>
+static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, const char *name13) {
+    if (t) t->mark(name13);
+    launch_tans_lds_class<N, ZB, 13>(d_units, n, stream);
+    if (t) t->mark("k_dec_tans_lds<other classes>");
+    launch_tans_lds_class<N, ZB, 14>(d_units, n, stream);
+    launch_tans_lds_class<N, ZB, 15>(d_units, n, stream);
 }
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
@@ -392,13 +401,12 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         mic_launch_dec_tables(d_units, n, stream);
     }
     if (variant != 100) {
-        if (t) t->mark("k_dec_tans_lds");
-        launch_tans_lds<2, false>(d_units, n, stream);
-        launch_tans_lds<4, false>(d_units, n, stream);
-        launch_tans_lds<8, false>(d_units, n, stream);
-        launch_tans_lds<2, true>(d_units, n, stream);
-        launch_tans_lds<4, true>(d_units, n, stream);
-        launch_tans_lds<8, true>(d_units, n, stream);
+        launch_tans_lds<2, false>(d_units, n, stream, t, "k_dec_tans_lds<2,false,13>");
+        launch_tans_lds<4, false>(d_units, n, stream, t, "k_dec_tans_lds<4,false,13>");
+        launch_tans_lds<8, false>(d_units, n, stream, t, "k_dec_tans_lds<8,false,13>");
+        launch_tans_lds<2, true>(d_units, n, stream, t, "k_dec_tans_lds<2,true,13>");
+        launch_tans_lds<4, true>(d_units, n, stream, t, "k_dec_tans_lds<4,true,13>");
+        launch_tans_lds<8, true>(d_units, n, stream, t, "k_dec_tans_lds<8,true,13>");
     }
     if (t) t->mark("k_dec_tans_serial");
     hipLaunchKernelGGL(k_dec_tans_serial, dim3(n), dim3(64), 0, stream, d_units);

@@ -839,7 +839,9 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
     }
 }
 
-__global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units, uint32_t tl_lo, uint32_t tl_hi) {
+template <int TLHI>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI)
+__global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units) {
+    constexpr uint32_t tl_lo = (TLHI == 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ uint16_t s_stab[];
     __shared__ uint16_t s_E[TE_THREADS][8];
     __shared__ uint32_t s_scan[TE_WAVES + 2];
@@ -952,14 +954,18 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     if (variant != 100) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr_done = true;
         }
-        if (t) t->mark("k_enc_tans_wg");
-        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 13, stream, d_units, 5u, 13u);
-        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 14, stream, d_units, 14u, 14u);
-        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 15, stream, d_units, 15u, 15u);
-        hipLaunchKernelGGL(k_enc_tans_wg, dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units, 16u, 16u);
+        if (t) t->mark("k_enc_tans_wg<13>");
+        hipLaunchKernelGGL(k_enc_tans_wg<13>, dim3(n), dim3(TE_THREADS), 2u << 13, stream, d_units);
+        if (t) t->mark("k_enc_tans_wg<other classes>");
+        hipLaunchKernelGGL(k_enc_tans_wg<14>, dim3(n), dim3(TE_THREADS), 2u << 14, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tans_wg<15>, dim3(n), dim3(TE_THREADS), 2u << 15, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tans_wg<16>, dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
     }
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
