@@ -20,6 +20,8 @@
 
 #define PX_THREADS 1024
 #define PX_WAVES (PX_THREADS / 64)
+#define PX_K 8                                    // pixels per thread per wavefront step
+struct __attribute__((packed, aligned(2))) PxVec { uint16_t v[PX_K]; };
 
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     __shared__ uint32_t s_scan[PX_WAVES + 1];
     __shared__ uint32_t s_fn[PX_WAVES + 1];
     __shared__ uint32_t s_misc[8];
-    __shared__ uint16_t s_row[2][PX_THREADS + 1];
+    __shared__ PxVec s_top[2][PX_THREADS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntok = u.ntok;
     const uint16_t *tok = u.tok;
@@ -165,46 +167,68 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     __syncthreads();
 
     // ---- phase 4: inverse predictor, skewed wavefront ---------------------------------------------
+    // Thread r owns row r of the band and works on the 8-pixel column group t - r at step t: its top
+    // neighbours were produced by thread r-1 one step earlier (LDS hand-off, one barrier per step, 8
+    // pixels per barrier), its left neighbour is its own previous pixel.  Symbols arrive and pixels
+    // leave as 16-byte vectors (2-byte aligned; gfx950 runs in unaligned-access mode), fetched two
+    // steps ahead so the L2 round trip is off the step's critical path.
+    const int ngrp = (W + PX_K - 1) / PX_K;
     for (int rb = 0; rb < H; rb += PX_THREADS) {
         const int y = rb + (int)tid;
         const bool row_ok = y < H;
         const int rows = min(H - rb, PX_THREADS);
-        const int steps = W + rows - 1;
+        const int steps = ngrp + rows - 1;
+        const size_t rowp = (size_t)y * (size_t)W;
         uint32_t left = 0;
-        // software prefetch of the next step's input symbol and raw bit
-        uint32_t nval = 0, nraw = 0;
-        {
-            const int c0 = 0 - (int)tid;
-            if (row_ok && c0 >= 0 && c0 < W) {
-                const uint32_t p = (uint32_t)y * (uint32_t)W + (uint32_t)c0;
-                nval = px[p]; nraw = (flags[p >> 5] >> (p & 31)) & 1;
-            }
-        }
+        auto fetch = [&](int g, PxVec &v, uint32_t &rawbits) {
+            v = PxVec{}; rawbits = 0;
+            if (!row_ok || g < 0 || g >= ngrp) return;
+            const size_t p = rowp + (size_t)g * PX_K;
+            if (g * PX_K + PX_K <= W) v = *(const PxVec *)(px + p);
+            else for (int k = 0; k < PX_K; k++) if (g * PX_K + k < W) v.v[k] = px[p + k];
+            // raw bits of pixels p .. p+7: two dwords, funnel-shifted
+            const uint32_t w0 = flags[p >> 5], w1 = flags[(p >> 5) + 1];
+            rawbits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (p & 31)) & 0xFFu;
+        };
+        PxVec v0, v1; uint32_t r0, r1;
+        fetch(0 - (int)tid, v0, r0);
+        fetch(1 - (int)tid, v1, r1);
         for (int t = 0; t < steps; t++) {
-            const int col = t - (int)tid;
-            const bool act = row_ok && col >= 0 && col < W;
-            const uint32_t val = nval, raw = nraw;
-            {   // prefetch for step t+1
-                const int c1 = col + 1;
-                if (row_ok && c1 >= 0 && c1 < W) {
-                    const uint32_t p = (uint32_t)y * (uint32_t)W + (uint32_t)c1;
-                    nval = px[p]; nraw = (flags[p >> 5] >> (p & 31)) & 1;
-                }
-            }
-            uint32_t res = 0;
+            const int g = t - (int)tid;
+            const bool act = row_ok && g >= 0 && g < ngrp;
+            const PxVec vin = v0; const uint32_t raw = r0;
+            v0 = v1; r0 = r1;
+            fetch(g + 2, v1, r1);                                      // two steps ahead
+            PxVec res = PxVec{};
             if (act) {
-                uint32_t top = 0;
-                if (y > 0) top = (tid > 0) ? s_row[(t + 1) & 1][tid - 1] : px[(uint32_t)(y - 1) * (uint32_t)W + (uint32_t)col];
-                int32_t pred;
-                if (col > 0 && y > 0) pred = (int32_t)((left + top) >> 1);
-                else if (col > 0) pred = (int32_t)left;
-                else if (y > 0) pred = (int32_t)top;
-                else pred = 0;
-                res = raw ? val : (uint32_t)(uint16_t)(pred + ((int32_t)val - (int32_t)thr));   // deltarlecompressu16.go:96-98
-                px[(uint32_t)y * (uint32_t)W + (uint32_t)col] = (uint16_t)res;
-                left = res;
+                const int c0 = g * PX_K;
+                PxVec top = PxVec{};
+                if (y > 0) {
+                    if (tid > 0) top = s_top[(t + 1) & 1][tid - 1];
+                    else {                                             // first row of a later band: previous band's last row
+                        const size_t q = (size_t)(y - 1) * (size_t)W + (size_t)c0;
+                        if (c0 + PX_K <= W) top = *(const PxVec *)(px + q);
+                        else for (int k = 0; k < PX_K; k++) if (c0 + k < W) top.v[k] = px[q + k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PX_K; k++) {
+                    const int col = c0 + k;
+                    int32_t pred;
+                    if (col > 0 && y > 0) pred = (int32_t)((left + (uint32_t)top.v[k]) >> 1);
+                    else if (col > 0) pred = (int32_t)left;
+                    else if (y > 0) pred = (int32_t)top.v[k];
+                    else pred = 0;
+                    const uint32_t val = vin.v[k];
+                    const uint32_t r = ((raw >> k) & 1) ? val : (uint32_t)(uint16_t)(pred + ((int32_t)val - (int32_t)thr));   // deltarlecompressu16.go:96-98
+                    res.v[k] = (uint16_t)r;
+                    if (col < W) left = r;
+                }
+                const size_t p = rowp + (size_t)c0;
+                if (c0 + PX_K <= W) *(PxVec *)(px + p) = res;
+                else for (int k = 0; k < PX_K; k++) if (c0 + k < W) px[p + k] = res.v[k];
             }
-            s_row[t & 1][tid] = (uint16_t)res;
+            s_top[t & 1][tid] = res;
             __syncthreads();
         }
         __threadfence_block();
