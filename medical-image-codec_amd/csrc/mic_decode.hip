@@ -219,23 +219,32 @@ __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
 // fse8state.go:230-380, rans8state.go:221-412) share ONE reverse bitstream, so the chain
 //   state_k -> table entry -> (nbBits, newState) -> bits at the running position -> state_k'
 // is serial per stream and a stream cannot be split (the format has no resynchronisation
-// points).  A lone wave issues one instruction every ~4-5 cycles whatever its
-// kind (tools/ubench_chain.hip: dependent ds_read 70 cycles, +30..45 cycles per added branch
-// or handful of scalar ops), so the loop is written for instruction COUNT:
-//   * all N look-ups of a group are issued together (one LDS round trip per N symbols);
-//   * the transition entry holds newState, nbBits and 32-nbBits ready-made: a state update is
-//     shift + add (3 VALU ops for the second state of a pair);
-//   * every lane computes the same values (no cross-lane traffic on the chain); the bit window
-//     and its refill live in SGPRs, the refill is branch-free but for the buffer switch;
-//   * the stream is prefetched 64 dwords per load into a lane-distributed register buffer;
-//   * the loop stages STATES (16 bit), not symbols; every 128 symbols all 64 lanes translate
-//     state -> symbol through the L2-resident symbol table and store 256 bytes coalesced, one
-//     chunk behind the chain so the gather latency is hidden.
-// LDS: chain[2^tl] u32 = newState << 16 | (32-nbBits) << 8 | nbBits ; stage[2][64] u32.
+// points).  Throughput = resident streams x chain speed, so the kernel is
+// built for (a) a short dependent chain, (b) few instructions (a lone wave issues one every
+// ~4-5 cycles, tools/ubench_chain.hip), (c) a small LDS footprint (streams per CU):
+//   * the table entry is the 16-bit `nextState` of the table construction
+//     (fsedecompressu16.go:233-241: newState = nextState << nbBits - tableSize,
+//     nbBits = tableLog - highBits(nextState)).  With states kept in [size, 2*size) the update
+//     is   state' = {nextState : window} >> (32 - nbBits),   nbBits = clz(nextState) - (31 - tableLog)
+//     = v_ffbh, v_sub, v_alignbit: three dependent VALU ops between two LDS reads.  16 KiB at
+//     tableLog 13 -> 9 streams per CU;
+//   * no scalar bit window: the compressed stream sits in a 256-dword LDS ring and the 32-bit
+//     window of a pair is a 2-dword LDS read at the running bit position, funnel-shifted
+//     (v_alignbit again).  That read is issued together with the table look-ups of the pair, so
+//     a pair costs one LDS round trip; no readfirstlane, no SALU chain, no branches in a chunk;
+//   * every lane computes the same values (the LDS reads are broadcasts); the 64 lanes differ
+//     only when they refill the ring (one 64-dword block per 128 symbols, prefetched a chunk
+//     ahead) and when they translate 128 staged states to symbols through the L2-resident
+//     symbol table, 256 bytes stored coalesced, one chunk behind the chain.
+// LDS: ring[256 + 1 mirror] u32 | stage[64] u32 (128 states) | chain[2^tl] u16.
+// Stream, symbol table and output are addressed as global (address_space(1)) pointers: a generic
+// (flat) load also counts on lgkmcnt, and the chain's LDS waits would then wait for HBM too.
 // ZB = table has 0-bit entries (zeroBits, fsedecompressu16.go:214-216).
-// grid = units, block = 64, dynamic LDS = 4 << tl_hi + 512.
+// grid = units, block = 64, dynamic LDS = 2 << tl_hi + TD_EXTRA.
 // TLHI names the table-size class of the launch (tableLog in (TLHI-1 .. TLHI], or <= 13): the classes
 // differ only in dynamic LDS, but distinct instantiations give each its own line in a kernel trace.
+#define TD_RING 256
+#define TD_EXTRA ((TD_RING + 4 + 64) * 4)
 template <int N, bool ZB, int TLHI>
 __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
     constexpr uint32_t tl_lo = (TLHI == 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
@@ -248,128 +257,144 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
     if (tl < tl_lo || tl > tl_hi) return;
     if ((u.zero_bits != 0) != ZB) return;
     if (u.ntok != 0) return;                                            // already decoded by another variant
+    if (u.bits_off >= u.comp_len) { if (threadIdx.x == 0) u.status = MICD_ERR_CORRUPT; return; }
+    const uint32_t len = u.comp_len - u.bits_off;
+    if (len >= (1u << 27)) return;                                      // bit positions are 32-bit here; the serial kernel takes it
     const uint32_t lane = threadIdx.x;
     const uint32_t size = 1u << tl;
-    uint32_t *chain = s_mem;
-    uint32_t *stage = s_mem + size;                                     // 2 x 64 dwords = 2 x 128 states
+    uint32_t *ring = s_mem;
+    uint32_t *stage = ring + TD_RING + 4;
+    uint16_t *chain = (uint16_t *)(stage + 64);
     {
         const uint32_t *dt = u.tt_nb;
-        for (uint32_t p = lane; p < size; p += 64) {
-            const uint32_t e = dt[p];                                   // newState | nbBits << 16
-            const uint32_t nb = e >> 16;
-            chain[p] = ((e & 0xFFFF) << 16) | ((32u - nb) << 8) | nb;
+        for (uint32_t p = lane * 2; p < size; p += 128) {
+            const uint2 e = *(const uint2 *)(dt + p);                   // newState | nbBits << 16
+            const uint32_t n0 = ((e.x & 0xFFFF) + size) >> (e.x >> 16);
+            const uint32_t n1 = ((e.y & 0xFFFF) + size) >> (e.y >> 16);
+            *(uint32_t *)(chain + p) = n0 | (n1 << 16);
         }
     }
-    __syncthreads();
-    const uint16_t *symg = u.tab_sym;                                   // state -> symbol, L2 resident
+    typedef const __attribute__((address_space(1))) uint16_t *gcu16;
+    typedef const __attribute__((address_space(1))) uint32_t *gcu32;
+    typedef __attribute__((address_space(1))) uint16_t *gu16;
+    typedef __attribute__((address_space(1))) uint32_t *gu32;
+    const gcu16 symg = (gcu16)(u.tab_sym - size);                       // indexed by state in [size, 2*size)
     const uint32_t count = u.count;
-    uint16_t *out = u.tok;
-    if (u.bits_off >= u.comp_len) { if (lane == 0) u.status = MICD_ERR_CORRUPT; return; }
+    const gu16 out = (gu16)u.tok;
     const uint8_t *bs = u.comp_in + u.bits_off;
-    const uint32_t len = u.comp_len - u.bits_off;
-    // readfirstlane: the byte comes back in a VGPR; everything derived from it (cursor, window,
-    // refill bookkeeping) is wave-uniform and must live in SGPRs / run on the scalar unit
-    const uint32_t last = __builtin_amdgcn_readfirstlane((uint32_t)bs[len - 1]);
+    const uint32_t last = bs[len - 1];
     if (last == 0) { if (lane == 0) u.status = MICD_ERR_CORRUPT; return; }  // bitreader.go:36-38
-    const uint64_t total_bits = 8ull * (len - 1) + (uint32_t)(31 - __clz(last));
-    // 4-byte aligned dword grid under the stream: grid bit 0 = LSB of g[0]
+    // 4-byte aligned dword grid under the stream: grid bit 0 = LSB of g[0]; unread bits = grid bits [8*sb, cur)
     const uintptr_t addr = (uintptr_t)bs;
     const uint32_t sb = (uint32_t)(addr & 3);
-    const uint32_t *g = (const uint32_t *)(addr - sb);
-    const uint64_t cur = total_bits + 8ull * sb;                        // unread bits are grid bits [8*sb, cur)
-    const int32_t top_dw = (int32_t)((cur - 1) >> 5);                   // dword holding the top unread bit (< 2^27)
-    int32_t di = top_dw;                                                // next dword to enter the window
-    // lane-distributed stream buffer: buf_a = the 64 dwords of block di>>6, buf_b = the block below
-    auto load_blk = [&](int32_t b) -> uint32_t {
+    const gcu32 g = (gcu32)(addr - sb);
+    const int32_t cur0 = (int32_t)(8u * (len - 1) + (uint32_t)(31 - __clz(last)) + 8u * sb);
+    const int32_t top_dw = (cur0 - 1) >> 5;                             // dword holding the top unread bit
+    auto load_blk = [&](int32_t b) -> uint32_t {                        // 64 dwords of block b, zero outside the stream
         const int32_t idx = b * 64 + (int32_t)lane;
         return (b >= 0 && idx <= top_dw) ? g[idx] : 0u;
     };
-    uint32_t buf_a = load_blk(di >> 6), buf_b = load_blk((di >> 6) - 1);
-    uint64_t W = 0; uint32_t avail = 0;
-    // take T (<= 32, uniform) bits off the window and top it up to >= 32 valid bits
-    auto advance = [&](uint32_t T) {
-        W <<= T; avail -= T;
-        const uint32_t nd = __builtin_amdgcn_readlane(buf_a, di & 63);
-        const bool need = avail < 32;
-        const uint64_t add = (uint64_t)nd << ((32u - avail) & 63u);
-        W |= need ? add : 0ull;
-        avail += need ? 32u : 0u;
-        const bool sw = need && ((di & 63) == 0);
-        di -= need ? 1 : 0;
-        if (sw) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 1); }     // every 64 refills
+    auto store_blk = [&](int32_t b, uint32_t v) {
+        const uint32_t slot = ((uint32_t)b & 3u) * 64u + lane;
+        ring[slot] = v;
+        if (slot == 0) ring[TD_RING] = v;                               // mirror: a 2-dword read at slot 255 stays linear
     };
-    {   // prime the window: the top dword holds 1..32 valid bits
-        const uint32_t top = (uint32_t)(cur - 32ull * (uint64_t)di);
-        W = (uint64_t)__builtin_amdgcn_readlane(buf_a, di & 63) << (64 - top);
-        avail = top;
-        const bool sw = (di & 63) == 0;
-        di--;
-        if (sw) { buf_a = buf_b; buf_b = load_blk((di >> 6) - 1); }
-        advance(0);
-    }
+    // window of a pair = grid bits [q, q+32): its MSB is the next unread bit
+    int32_t q = cur0 - 32;
+    int32_t blk = (q >> 5) >> 6;                                        // block of the window's low dword at chunk start
+    store_blk(blk + 1, load_blk(blk + 1));
+    store_blk(blk, load_blk(blk));
+    store_blk(blk - 1, load_blk(blk - 1));
+    uint32_t pf = load_blk(blk - 2);                                    // enters the ring at the end of the chunk
+    __syncthreads();
+    // The ring sits at LDS address 0 (dynamic LDS of a kernel without static LDS; checked below), so the
+    // byte address of its dword is a shift and a mask of q with no base to add.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring != 0u) { if (lane == 0) u.status = MICD_ERR_INTERNAL; return; }
+    auto window = [&](int32_t qq) -> uint32_t {
+        typedef const __attribute__((address_space(3))) uint32_t *lcu32;
+        const lcu32 w = (lcu32)(uintptr_t)(((uint32_t)qq >> 3) & ((TD_RING - 1) * 4u));
+        return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)qq);    // shift = qq & 31
+    };
+    const uint32_t C = 31u - tl;
+    const uint16_t *chain_o = chain - size;                             // states carry the +size offset
     uint32_t st[N];
-    // initial states: state 0 first, tl bits each (fse2state.go:210-212)
+    // initial states: state 0 first, tl bits each (fse2state.go:210-212); kept with the +size offset
 #pragma unroll
-    for (int p = 0; p < N; p += 2) {
-        const uint32_t hi = (uint32_t)(W >> 32);
-        st[p] = __builtin_amdgcn_ubfe(hi, 32u - tl, tl);
-        st[p + 1] = __builtin_amdgcn_ubfe(hi, 32u - 2u * tl, tl);
-        advance(2u * tl);
+    for (int p = 0; p < N; p++) {
+        st[p] = size + (window(q) >> (32u - tl));
+        q -= (int32_t)tl;
     }
-    // one group = N symbols, states 0..N-1 in order; bits are handed out pair by pair (<= 32 a pair)
-    auto group = [&](uint32_t *stage_w, uint32_t r) {                   // r = symbols wanted from this group (N, or fewer in the tail)
+    // one group = N symbols, states 0..N-1 in order; a pair takes <= 30 bits off one 32-bit window
+    auto group = [&](uint32_t *stage_w) {
         uint32_t e[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) e[k] = chain[st[k]];
+        for (int k = 0; k < N; k++) e[k] = chain_o[st[k]];
 #pragma unroll
         for (int p = 0; p < N; p += 2) {
-            const uint32_t hi = (uint32_t)(W >> 32);
+            const uint32_t hi = window(q);
             stage_w[p >> 1] = st[p] | (st[p + 1] << 16);
-            uint32_t nb0 = e[p] & 0xFF, nb1 = e[p + 1] & 0xFF;
-            if (r < (uint32_t)N) { nb0 = ((uint32_t)p < r) ? nb0 : 0u; nb1 = ((uint32_t)p + 1 < r) ? nb1 : 0u; }
-            uint32_t b0, b1;
-            if (ZB || r < (uint32_t)N) {
-                b0 = __builtin_amdgcn_ubfe(hi, 32u - nb0, nb0);
-                b1 = __builtin_amdgcn_ubfe(hi, 32u - nb0 - nb1, nb1);
-            } else {                                                    // nbBits >= 1: plain shifts
-                b0 = hi >> ((e[p] >> 8) & 0xFF);
-                b1 = (hi << nb0) >> ((e[p + 1] >> 8) & 0xFF);
+            // m = -nbBits (nextState >= 1, so clz is defined); a funnel shift right by m mod 32 = 32 - nbBits
+            // both appends the bits to nextState and moves the window on to the second state
+            const uint32_t m0 = C - (uint32_t)__builtin_clz(e[p]), m1 = C - (uint32_t)__builtin_clz(e[p + 1]);
+            if (ZB) {                                                   // nbBits may be 0: 64-bit shift by 32 is well defined
+                const uint32_t hi1 = hi << (0u - m0);
+                st[p] = (uint32_t)((((uint64_t)e[p] << 32) | hi) >> (32u + m0));
+                st[p + 1] = (uint32_t)((((uint64_t)e[p + 1] << 32) | hi1) >> (32u + m1));
+            } else {
+                const uint32_t hi1 = __builtin_amdgcn_alignbit(hi, 0u, m0);   // hi << nbBits0
+                st[p] = __builtin_amdgcn_alignbit(e[p], hi, m0);
+                st[p + 1] = __builtin_amdgcn_alignbit(e[p + 1], hi1, m1);
             }
-            st[p] = b0 + (e[p] >> 16);
-            st[p + 1] = b1 + (e[p + 1] >> 16);
-            advance(__builtin_amdgcn_readfirstlane(nb0 + nb1));
+            q += (int32_t)m0 + (int32_t)m1;
         }
     };
+    // one symbol with state k (tail: fse2state.go:293-305 and siblings)
+    auto single = [&](int k, uint16_t *stage_h) {
+        const uint32_t e = chain_o[st[k]];
+        const uint32_t hi = window(q);
+        *stage_h = (uint16_t)st[k];
+        const uint32_t nb = (uint32_t)__builtin_clz(e) - C;
+        st[k] = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
+        q -= (int32_t)nb;
+    };
+    // ring upkeep between chunks: a chunk of 128 symbols moves q down by at most 128 * 15 bits = 60 dwords,
+    // so with blocks blk+1, blk, blk-1 present at its start every window read of the chunk is served; the
+    // block below was fetched during the chunk and goes into the free slot now
+    // (order at a chunk end: consume the old prefetch, store the old gather, then issue the new loads,
+    // so every wait on a memory counter is for a load that has had a whole chunk to come back)
     constexpr uint32_t G = 128 / N;                                     // groups per 128-symbol chunk
     const uint32_t chunks = count / 128;
-    uint32_t pend = 0; bool have_pend = false;                          // symbols gathered for the previous chunk
+    uint32_t pend_lo = 0, pend_hi = 0; bool have_pend = false;          // symbols gathered for the previous chunk (joined only
+                                                                        // at the store: joining earlier would wait for the gather)
     uint32_t obase = 0;                                                 // dword index of the pending chunk in out
     for (uint32_t ch = 0; ch < chunks; ch++) {
-        uint32_t *sw = stage + (ch & 1) * 64;
-#pragma unroll 4
-        for (uint32_t gi = 0; gi < G; gi++) group(sw + gi * (N / 2), N);
+#pragma unroll 8
+        for (uint32_t gi = 0; gi < G; gi++) group(stage + gi * (N / 2));
         // this chunk's 128 states are staged: write out the previous chunk, gather this one
-        if (have_pend) ((uint32_t *)out)[obase + lane] = pend;
-        const uint32_t s2 = sw[lane];
-        pend = (uint32_t)symg[s2 & 0xFFFF] | ((uint32_t)symg[s2 >> 16] << 16);
+        store_blk(blk - 2, pf);
+        if (have_pend) ((gu32)out)[obase + lane] = pend_lo | (pend_hi << 16);
+        blk = (q >> 5) >> 6;
+        pf = load_blk(blk - 2);
+        const uint32_t s2 = stage[lane];
+        pend_lo = symg[s2 & 0xFFFF]; pend_hi = symg[s2 >> 16];
         have_pend = true; obase = ch * 64;
     }
-    if (have_pend) ((uint32_t *)out)[obase + lane] = pend;
-    // tail: count % 128 symbols (fse2state.go:293-305 for the last partial group)
+    if (have_pend) ((gu32)out)[obase + lane] = pend_lo | (pend_hi << 16);
+    // tail: count % 128 symbols; whole groups, then the last partial group state by state
     {
         const uint32_t done = chunks * 128;
         const uint32_t rem = count - done;
-        uint32_t *sw = stage + (chunks & 1) * 64;
         uint32_t k = 0;
-        for (; k + N <= rem; k += N) group(sw + (k / 2), N);
-        if (k < rem) group(sw + (k / 2), rem - k);
-        const uint16_t *st16 = (const uint16_t *)sw;
+        for (; k + N <= rem; k += N) group(stage + (k / 2));
+        uint16_t *st16 = (uint16_t *)stage;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) if (k + (uint32_t)j < rem) single(j, st16 + k + j);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         for (uint32_t j = lane; j < rem; j += 64) out[done + j] = symg[st16[j]];
     }
     if (lane == 0) {
-        // bits taken = total - (bits still in the window + bits in dwords not yet fetched)
-        const int64_t unread = (int64_t)avail + 32ll * ((int64_t)di + 1) - 8ll * sb;
-        if (unread < 0) u.status = MICD_ERR_CORRUPT;                    // bitreader.go:113-120
+        // bits still unread = grid bits [8*sb, q+32)
+        if (q + 32 - (int32_t)(8u * sb) < 0) u.status = MICD_ERR_CORRUPT;   // bitreader.go:113-120
         else u.ntok = count;
     }
 }
@@ -378,10 +403,10 @@ template <int N, bool ZB, int TLHI>
 static void launch_tans_lds_class(MicUnit *d_units, int n, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB, TLHI>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB, TLHI>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB, TLHI>), dim3(n), dim3(64), (4u << TLHI) + 512, stream, d_units);
+    hipLaunchKernelGGL((k_dec_tans_lds<N, ZB, TLHI>), dim3(n), dim3(64), (2u << TLHI) + TD_EXTRA, stream, d_units);
 }
 template <int N, bool ZB>
 static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, const char *name13) {

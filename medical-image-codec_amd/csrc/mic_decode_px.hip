@@ -57,6 +57,9 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     uint2 *seg = u.seg;
     uint16_t *sym = u.sym;
 
+#ifdef MIC_STAMP
+    const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 1: header walk (wave 0) -----------------------------------------------------
     if (wave == 0) {
         uint32_t pos = 1, outp = 0, nseg = 0, err = 0;
@@ -85,6 +88,9 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     const uint32_t nseg = s_misc[0], nsym = s_misc[1];
     if (s_misc[2]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
 
+#ifdef MIC_STAMP
+    const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 2: expansion ------------------------------------------------------------------
     {
         uint32_t bad = 0;
@@ -115,6 +121,9 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     uint16_t *px = u.px_out;
     uint32_t *flags = u.flags;
 
+#ifdef MIC_STAMP
+    const uint64_t st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 3: escape markers and pixel numbering -------------------------------------------
     {
         uint32_t carry_marker = 0;       // marker state of the symbol before the tile
@@ -166,6 +175,9 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     __threadfence_block();
     __syncthreads();
 
+#ifdef MIC_STAMP
+    const uint64_t st3 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 4: inverse predictor, skewed wavefront ---------------------------------------------
     // Thread r owns row r of the band and works on the 8-pixel column group t - r at step t: its top
     // neighbours were produced by thread r-1 one step earlier (LDS hand-off, one barrier per step, 8
@@ -234,6 +246,13 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
         __threadfence_block();
         __syncthreads();
     }
+#ifdef MIC_STAMP
+    if (tid == 0) {
+        const uint64_t st4 = __builtin_amdgcn_s_memtime();
+        u.max_count = (uint32_t)(st1 - st0); u.hdr_len = (uint32_t)(st2 - st1); u.zero_bits = (uint32_t)(st3 - st2); u.flavour = (uint32_t)(st4 - st3);
+        u.nseg = nseg; u.nsym = nsym;
+    }
+#endif
 }
 
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream) {

@@ -1,4 +1,4 @@
-"""Diagnostic (MIC_STAMP build only): cycles per group of the tANS decode main loop."""
+"""Diagnostic (build with EXTRA_FLAGS=-DMIC_STAMP): s_memtime ticks (100 MHz) per phase of k_dec_pixels_wg."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ sess = mic.Session(len(units), W * 256); cu = mic.Session.make_units(units)
 sess.encode_enqueue(d_px.data_ptr(), cu); d_blobs, offs, st, ns = sess.encode_finish(); assert (st == 0).all()
 sess.decode_enqueue(d_blobs, offs, cu, d_out.data_ptr()); assert (sess.decode_finish() == 0).all()
 assert torch.equal(d_out, d_px)
-buf = (C.c_uint32 * 8)()
+buf = (C.c_uint32 * 16)()
 for i in range(len(units)):
     mic.lib().mic_hip_debug_unit(sess._h, i, buf)
-    print(f"unit {i}: ntok={buf[0]} tl={buf[2]} symlen={buf[3]} loop_ticks={buf[4]} groups={buf[5]} ticks/group={buf[4]/max(buf[5],1):.1f}")
+    print(f"unit {i}: ntok={buf[0]} nseg={buf[12]} nsym={buf[13]} ticks: walk={buf[4]} expand={buf[5]} scan={buf[6]} wavefront={buf[7]}")
