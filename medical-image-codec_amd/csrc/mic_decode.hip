@@ -439,8 +439,7 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         if (t) t->mark("k_dec_pixels_serial");
         hipLaunchKernelGGL(k_dec_pixels_serial, dim3(n), dim3(64), 0, stream, d_units);
     } else {
-        if (t) t->mark("k_dec_pixels_wg");
-        mic_launch_decode_pixels(d_units, n, stream);
+        mic_launch_decode_pixels(d_units, n, stream, t);
     }
     if (t) t->mark("end");
 }

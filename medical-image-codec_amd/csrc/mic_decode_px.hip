@@ -20,7 +20,9 @@
 
 #define PX_THREADS 1024
 #define PX_WAVES (PX_THREADS / 64)
-#define PX_K 8                                    // pixels per thread per wavefront step
+#define PX_K 8                                    // pixels per thread per wavefront step (in-work-group fallback)
+#define PR_K 32                                   // pixels per lane per step in k_dec_predict
+#define PR_MAX_W 32768                            // its row buffer is 2 bytes per column of LDS
 struct __attribute__((packed, aligned(2))) PxVec { uint16_t v[PX_K]; };
 
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, uint32_t lane) {
@@ -120,6 +122,7 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     const uint32_t delim = (1u << depth) - 1;
     uint16_t *px = u.px_out;
     uint32_t *flags = u.flags;
+    if (tid == 0) u.dec_thr = thr;
 
 #ifdef MIC_STAMP
     const uint64_t st2 = __builtin_amdgcn_s_memtime();
@@ -184,6 +187,8 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     // pixels per barrier), its left neighbour is its own previous pixel.  Symbols arrive and pixels
     // leave as 16-byte vectors (2-byte aligned; gfx950 runs in unaligned-access mode), fetched two
     // steps ahead so the L2 round trip is off the step's critical path.
+    // Frames up to PR_MAX_W columns leave here: k_dec_predict does this phase one wave per unit.
+    if (W <= PR_MAX_W) return;
     const int ngrp = (W + PX_K - 1) / PX_K;
     for (int rb = 0; rb < H; rb += PX_THREADS) {
         const int y = rb + (int)tid;
@@ -255,6 +260,214 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
 #endif
 }
 
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream) {
+
+// ==========================================================================================
+// Phase 4 as its own kernel: inverse Delta(avg) predictor, one wave per unit.
+//
+//   out[y][x] = raw ? sym : ((left + top) >> 1) + sym - thr        (deltarlecompressu16.go:83-99;
+//   left only on row 0, top only in column 0, 0 at the origin), 16-bit wrap-around.
+//
+// Lane r owns rows r, r+64, r+128, ... and walks each in groups of 32 pixels (64 bytes); at step t
+// it is at virtual index t - r of its sequence (band b = index / P, group g = index % P, P =
+// max(groups per row, 64)).  Its top neighbours were produced by lane r-1 one step earlier and
+// arrive by DPP wave_shr:1; lane 0's come from lane 63 of the band before, through a row buffer in
+// LDS that lane 63 fills as it goes (P >= 64 makes that hand-off causal).  Row 0 of the unit is a
+// segmented prefix sum, computed up front into the same row buffer, so lane 0 simply copies it.
+// Per step a lane reads 64 contiguous bytes of symbols (2-byte aligned vector loads, fetched three
+// steps ahead) and writes 64 bytes of pixels: every cache line is consumed whole within two steps.
+// Escapes are rare: a step takes the select-free path unless some lane of the wave holds a raw pixel.
+typedef uint32_t pr_v4 __attribute__((ext_vector_type(4)));
+typedef uint32_t pr_v2 __attribute__((ext_vector_type(2)));
+typedef pr_v4 PrQ __attribute__((aligned(2)));                // 2-byte aligned vector accesses (gfx950: unaligned mode)
+typedef pr_v2 PrD __attribute__((aligned(2)));
+typedef uint32_t PrS __attribute__((aligned(2)));
+typedef __attribute__((address_space(1))) uint16_t *pr_gu16;
+
+// cnt (1..32, wave-uniform) pixels of a group, packed two per dword
+__device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[16], int cnt) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = 4 * q;
+        pr_gu16 o = dst + 8 * q;
+        if (cnt >= 8 * q + 8) {
+            pr_v4 v; v.x = d[j]; v.y = d[j + 1]; v.z = d[j + 2]; v.w = d[j + 3];
+            *(__attribute__((address_space(1))) PrQ *)o = v;
+        } else if (cnt > 8 * q) {
+            const int r = cnt - 8 * q;
+            if (r & 4) {
+                pr_v2 v; v.x = d[j]; v.y = d[j + 1];
+                *(__attribute__((address_space(1))) PrD *)o = v;
+                if (r & 2) { *(__attribute__((address_space(1))) PrS *)(o + 4) = d[j + 2]; if (r & 1) o[6] = (uint16_t)d[j + 3]; }
+                else if (r & 1) o[4] = (uint16_t)d[j + 2];
+            } else if (r & 2) {
+                *(__attribute__((address_space(1))) PrS *)o = d[j];
+                if (r & 1) o[2] = (uint16_t)d[j + 1];
+            } else {
+                o[0] = (uint16_t)d[j];
+            }
+        }
+    }
+}
+
+struct PrSlot {
+    uint32_t d[16];       // 32 symbols
+    uint32_t raw;         // bit k: pixel k is stored raw
+    int32_t g, y;         // group and row; g < 0 or act == 0: nothing to do
+    uint32_t p;           // pixel index of the group's first pixel
+    uint32_t act;
+};
+
+__global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, int w_hi) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.mode != 0) return;
+    const int W = u.w, H = u.h;
+    if (W <= w_lo || W > w_hi) return;
+    extern __shared__ uint32_t s_rowbuf[];                       // ngrp x 16 dwords
+    const uint32_t lane = threadIdx.x;
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    const uint32_t thr = u.dec_thr;
+    const pr_gu16 px = (pr_gu16)u.px_out;
+    const __attribute__((address_space(1))) uint32_t *flags = (const __attribute__((address_space(1))) uint32_t *)u.flags;
+    const int ngrp = (W + PR_K - 1) / PR_K;
+    const int tail = W - (ngrp - 1) * PR_K;                      // pixels in the last group of a row, 1..32
+    const int P = max(ngrp, 64);
+    const int nb = (H + 63) >> 6;
+
+    // ---- row 0: out[x] = raw ? sym : out[x-1] + sym - thr, out[-1] = 0; a scan of (reset, sum) pairs ----
+    {
+        uint16_t *row16 = (uint16_t *)s_rowbuf;
+        for (int x = (int)lane; x < ngrp * PR_K; x += 64) row16[x] = (x < W) ? px[x] : (uint16_t)0;
+        __syncthreads();
+        const int cw = (W + 63) >> 6;
+        const int x0 = min(W, (int)lane * cw), x1 = min(W, x0 + cw);
+        uint32_t rs = 0, sum = 0;
+        for (int x = x0; x < x1; x++) {
+            const uint32_t raw = (flags[x >> 5] >> (x & 31)) & 1u, v = row16[x];
+            if (raw) { rs = 1; sum = v; } else sum = (sum + v - thr) & 0xFFFFu;
+        }
+        // inclusive scan of the composition (a then b) = b.reset ? b : (a.reset, a.sum + b.sum)
+        uint32_t is = sum, ir = rs;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t os = __shfl_up(is, dd), orr = __shfl_up(ir, dd);
+            if (lane >= (uint32_t)dd && !ir) { is = (is + os) & 0xFFFFu; ir = orr; }
+        }
+        uint32_t cur = __shfl_up(is, 1);
+        if (lane == 0) cur = 0;
+        for (int x = x0; x < x1; x++) {
+            const uint32_t raw = (flags[x >> 5] >> (x & 31)) & 1u, v = row16[x];
+            cur = raw ? v : ((cur + v - thr) & 0xFFFFu);
+            row16[x] = (uint16_t)cur;
+        }
+        __syncthreads();
+    }
+
+    // ---- the pipeline ----
+    int32_t cg = -(int32_t)lane, cb = 0;                         // cursor of the NEXT group to fetch
+    auto fetch = [&](PrSlot &s) {
+        const int32_t y = (int32_t)lane + 64 * cb;
+        s.g = cg; s.y = y;
+        s.act = (cg >= 0 && cg < ngrp && cb < nb && y < H) ? 1u : 0u;
+        s.p = (uint32_t)y * (uint32_t)W + (uint32_t)cg * PR_K;
+        s.raw = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) s.d[i] = 0;
+        if (s.act) {
+            const pr_gu16 src = px + s.p;
+            if (s.p + PR_K <= npx) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const pr_v4 v = *(const __attribute__((address_space(1))) PrQ *)(src + 8 * q);
+                    s.d[4 * q] = v.x; s.d[4 * q + 1] = v.y; s.d[4 * q + 2] = v.z; s.d[4 * q + 3] = v.w;
+                }
+            } else {                                             // last row's tail: stay inside the buffer
+                for (int k = 0; k < PR_K; k++) if (s.p + (uint32_t)k < npx) {
+                    const uint32_t v = src[k];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) if (i == (k >> 1)) s.d[i] |= v << (16 * (k & 1));
+                }
+            }
+            const uint32_t w0 = flags[s.p >> 5], w1 = flags[(s.p >> 5) + 1];
+            s.raw = __builtin_amdgcn_alignbit(w1, w0, s.p);      // bits of pixels p .. p+31
+            if (y == 0) s.raw = 0xFFFFFFFFu;                     // row 0 comes ready-made from the row buffer
+        }
+        if (++cg == P) { cg = 0; cb++; }
+    };
+    uint32_t last[16];                                           // this lane's previous result = next lane's top
+#pragma unroll
+    for (int i = 0; i < 16; i++) last[i] = 0;
+    uint32_t left = 0;
+    auto step = [&](const PrSlot &s) {
+        // top neighbours: lane r-1's previous result; lane 0 takes the row buffer entry of its group
+        uint32_t top[16];
+        {
+            const int32_t gc = min(max(s.g, 0), ngrp - 1);
+            const uint4 *rb4 = (const uint4 *)(s_rowbuf + gc * 16);
+            uint32_t lv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) lv[i] = 0;
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint4 v = rb4[q]; lv[4 * q] = v.x; lv[4 * q + 1] = v.y; lv[4 * q + 2] = v.z; lv[4 * q + 3] = v.w; }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) top[i] = __builtin_amdgcn_update_dpp(lv[i], last[i], 0x138, 0xF, 0xF, false);   // wave_shr:1
+        }
+        uint32_t res[16];
+        if (s.g == 0) left = top[0] & 0xFFFFu;                   // column 0: predictor = top ((top+top)>>1)
+        const bool any_raw = __any(s.act && s.raw != 0);
+        if (!any_raw) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
+                const uint32_t c0 = (s.d[i] & 0xFFFFu) - thr, c1 = (s.d[i] >> 16) - thr;
+                const uint32_t r0 = (((left + t0) >> 1) + c0) & 0xFFFFu;
+                const uint32_t r1 = (((r0 + t1) >> 1) + c1) & 0xFFFFu;
+                res[i] = r0 | (r1 << 16);
+                left = r1;
+            }
+        } else {
+            const bool row0 = s.y == 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t src = row0 ? top[i] : s.d[i];
+                const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
+                const uint32_t v0 = src & 0xFFFFu, v1 = src >> 16;
+                const uint32_t r0 = ((s.raw >> (2 * i)) & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
+                const uint32_t r1 = ((s.raw >> (2 * i + 1)) & 1u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
+                res[i] = r0 | (r1 << 16);
+                left = r1;
+            }
+        }
+        if (s.act) {
+            const pr_gu16 dst = px + s.p;
+            if (s.g < ngrp - 1 || tail == PR_K) pr_store_cnt(dst, res, PR_K);
+            else pr_store_cnt(dst, res, tail);
+            if (lane == 63) {
+                uint4 *rb4 = (uint4 *)(s_rowbuf + s.g * 16);
+#pragma unroll
+                for (int q = 0; q < 4; q++) rb4[q] = make_uint4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) last[i] = res[i];
+    };
+    PrSlot sa, sb, sc;
+    fetch(sa); fetch(sb); fetch(sc);
+    const int steps = nb * P + 63;
+    for (int t = 0; t < steps; t += 3) {
+        step(sa); fetch(sa);
+        step(sb); fetch(sb);
+        step(sc); fetch(sc);
+    }
+}
+
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t) {
+    if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
+    // two row-buffer classes so that ordinary widths keep many waves per CU
+    if (t) t->mark("k_dec_predict");
+    hipLaunchKernelGGL(k_dec_predict, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - PR_K);
+    if (t) t->mark("k_dec_predict<wide>");
+    hipLaunchKernelGGL(k_dec_predict, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, 8192 - PR_K, PR_MAX_W);
 }

@@ -53,6 +53,7 @@ struct MicUnit {
     uint32_t *flags;          // decode: 1 bit per pixel, set = pixel stored raw behind an escape
     uint32_t  nseg;
     uint32_t  nsym;
+    uint32_t  dec_thr;        // decode: delta threshold (1 << (depth-1)) - 1 of the stream's own max value
     // ---- results -----------------------------------------------------------------
     uint32_t ntok;            // number of u16 in tok
     uint32_t blob_len;

@@ -27,6 +27,6 @@ struct MicTimer {
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream);
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t);
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream);
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream);
