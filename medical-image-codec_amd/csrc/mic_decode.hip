@@ -362,6 +362,37 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
     // block below was fetched during the chunk and goes into the free slot now
     // (order at a chunk end: consume the old prefetch, store the old gather, then issue the new loads,
     // so every wait on a memory counter is for a load that has had a whole chunk to come back)
+    // Header walker (frames only): the RLE headers of the token stream form a linked list
+    // (rledecompressu16.go:59-85); following it here, on tokens that are still in registers, costs a
+    // compare per chunk where runs are long, and spares k_dec_pixels_wg a chain of dependent HBM reads.
+    // Same stop and error rules as that kernel's own walk, which still runs when this one gives up.
+    bool w_on = u.mode == 0 && u.seg != nullptr;
+    bool w_err = false;
+    uint32_t w_pos = 0, w_out = 0, w_nseg = 0, w_mid = 0;
+    const uint32_t w_symcap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u), w_segcap = u.seg_cap;
+    typedef uint32_t w_v2 __attribute__((ext_vector_type(2)));
+    __attribute__((address_space(1))) w_v2 *const w_seg = (__attribute__((address_space(1))) w_v2 *)u.seg;
+    auto walk = [&](uint32_t cend, auto get) {                          // headers in front of token cend
+        while (w_on && w_pos < cend) {
+            const uint32_t h = get(w_pos);
+            if (w_pos == 0) {                                           // token 0 fixes the run/literal split
+                const int d0 = mic_len16((uint16_t)h);
+                if (d0 == 0) { w_on = false; w_err = true; break; }
+                w_mid = (1u << (d0 - 1)) - 1; w_pos = 1;
+                continue;
+            }
+            if (w_out >= w_symcap) { w_on = false; break; }
+            if (h == 0 || w_nseg >= w_segcap) { w_on = false; w_err = true; break; }
+            if (h <= w_mid) {
+                if (w_pos + 1 >= count) { w_on = false; w_err = true; break; }
+                if (lane == 0) { w_v2 r; r.x = (w_pos + 1) | 0x80000000u; r.y = w_out; w_seg[w_nseg] = r; }
+                w_nseg++; w_out += h; w_pos += 2;
+            } else {
+                if (lane == 0) { w_v2 r; r.x = w_pos + 1; r.y = w_out; w_seg[w_nseg] = r; }
+                w_nseg++; w_out += h - w_mid; w_pos += 1 + (h - w_mid);
+            }
+        }
+    };
     constexpr uint32_t G = 128 / N;                                     // groups per 128-symbol chunk
     const uint32_t chunks = count / 128;
     uint32_t pend_lo = 0, pend_hi = 0; bool have_pend = false;          // symbols gathered for the previous chunk (joined only
@@ -372,14 +403,32 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
         for (uint32_t gi = 0; gi < G; gi++) group(stage + gi * (N / 2));
         // this chunk's 128 states are staged: write out the previous chunk, gather this one
         store_blk(blk - 2, pf);
-        if (have_pend) ((gu32)out)[obase + lane] = pend_lo | (pend_hi << 16);
+        if (have_pend) {
+            const uint32_t pk = pend_lo | (pend_hi << 16);
+            ((gu32)out)[obase + lane] = pk;
+            const uint32_t cb = obase * 2;
+            walk(cb + 128, [&](uint32_t pos) -> uint32_t {
+                const uint32_t rel = pos - cb;
+                const uint32_t pair = __builtin_amdgcn_readlane(pk, rel >> 1);
+                return (rel & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+            });
+        }
         blk = (q >> 5) >> 6;
         pf = load_blk(blk - 2);
         const uint32_t s2 = stage[lane];
         pend_lo = symg[s2 & 0xFFFF]; pend_hi = symg[s2 >> 16];
         have_pend = true; obase = ch * 64;
     }
-    if (have_pend) ((gu32)out)[obase + lane] = pend_lo | (pend_hi << 16);
+    if (have_pend) {
+        const uint32_t pk = pend_lo | (pend_hi << 16);
+        ((gu32)out)[obase + lane] = pk;
+        const uint32_t cb = obase * 2;
+        walk(cb + 128, [&](uint32_t pos) -> uint32_t {
+            const uint32_t rel = pos - cb;
+            const uint32_t pair = __builtin_amdgcn_readlane(pk, rel >> 1);
+            return (rel & 1) ? (pair >> 16) : (pair & 0xFFFFu);
+        });
+    }
     // tail: count % 128 symbols; whole groups, then the last partial group state by state
     {
         const uint32_t done = chunks * 128;
@@ -390,12 +439,21 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
 #pragma unroll
         for (int j = 0; j < N - 1; j++) if (k + (uint32_t)j < rem) single(j, st16 + k + j);
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        for (uint32_t j = lane; j < rem; j += 64) out[done + j] = symg[st16[j]];
+        uint32_t tv0 = 0, tv1 = 0;
+        if (lane < rem) { tv0 = symg[st16[lane]]; out[done + lane] = (uint16_t)tv0; }
+        if (lane + 64 < rem) { tv1 = symg[st16[lane + 64]]; out[done + lane + 64] = (uint16_t)tv1; }
+        walk(count, [&](uint32_t pos) -> uint32_t {
+            const uint32_t rel = pos - done;
+            return (rel < 64) ? __builtin_amdgcn_readlane(tv0, rel) : __builtin_amdgcn_readlane(tv1, rel - 64);
+        });
     }
     if (lane == 0) {
         // bits still unread = grid bits [8*sb, q+32)
         if (q + 32 - (int32_t)(8u * sb) < 0) u.status = MICD_ERR_CORRUPT;   // bitreader.go:113-120
-        else u.ntok = count;
+        else {
+            u.ntok = count;
+            if (u.mode == 0 && u.seg != nullptr && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_symcap); u.walk_ok = 1; }
+        }
     }
 }
 

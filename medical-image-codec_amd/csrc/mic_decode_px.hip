@@ -20,6 +20,8 @@
 
 #define PX_THREADS 1024
 #define PX_WAVES (PX_THREADS / 64)
+#define PX_T 8192                                 // symbols per tile of the expansion / numbering pass
+#define PX_SPT (PX_T / PX_THREADS)                // symbols per thread
 #define PX_K 8                                    // pixels per thread per wavefront step (in-work-group fallback)
 #define PR_K 32                                   // pixels per lane per step in k_dec_predict
 #define PR_MAX_W 32768                            // its row buffer is 2 bytes per column of LDS
@@ -42,10 +44,12 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t g, uint32_t f) {
 __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.mode != 0) return;
-    __shared__ uint32_t s_scan[PX_WAVES + 1];
     __shared__ uint32_t s_fn[PX_WAVES + 1];
     __shared__ uint32_t s_misc[8];
-    __shared__ PxVec s_top[2][PX_THREADS];
+    __shared__ uint32_t s_segx[PX_THREADS], s_segy[PX_THREADS + 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tiles[2][PX_T + 8];   // symbols in, pixels out
+    uint16_t *s_px = s_tiles[1];
+    PxVec (*s_top)[PX_THREADS] = (PxVec (*)[PX_THREADS])&s_tiles[0][0];       // wide-frame fallback, after the tiles are done
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ntok = u.ntok;
     const uint16_t *tok = u.tok;
@@ -57,13 +61,14 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     const uint32_t mid = (1u << (d0 - 1)) - 1;
     const uint32_t symcap = min(u.sym_cap, 2u * npx + 2u);
     uint2 *seg = u.seg;
-    uint16_t *sym = u.sym;
 
 #ifdef MIC_STAMP
     const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- phase 1: header walk (wave 0) -----------------------------------------------------
-    if (wave == 0) {
+    if (u.walk_ok) {                                                    // k_dec_tans_lds walked the headers as it produced them
+        if (tid == 0) { s_misc[0] = u.nseg; s_misc[1] = u.nsym; s_misc[2] = 0; s_misc[3] = 0; }
+    } else if (wave == 0) {
         uint32_t pos = 1, outp = 0, nseg = 0, err = 0;
         const uint32_t segcap = u.seg_cap;
         while (pos < ntok && outp < symcap && !err) {
@@ -75,10 +80,10 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
                 if (h <= mid) {                                          // same-run: count, value
                     if (pos + j + 1 >= ntok) { err = 1; break; }
                     if (j == 63) break;                                  // value not in the window: reload at the header
-                    if (lane == 0) seg[nseg] = make_uint2(pos + j, outp);
+                    if (lane == 0) seg[nseg] = make_uint2((pos + j + 1) | 0x80000000u, outp);
                     nseg++; outp += h; j += 2;
                 } else {                                                 // literal run
-                    if (lane == 0) seg[nseg] = make_uint2(pos + j, outp);
+                    if (lane == 0) seg[nseg] = make_uint2(pos + j + 1, outp);
                     nseg++; outp += h - mid; j += 1 + (h - mid);
                 }
             }
@@ -92,30 +97,13 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
 
 #ifdef MIC_STAMP
     const uint64_t st1 = __builtin_amdgcn_s_memtime();
+    const uint64_t st2 = st1;
 #endif
-    // ---- phase 2: expansion ------------------------------------------------------------------
-    {
-        uint32_t bad = 0;
-        for (uint32_t si = wave; si < nseg; si += PX_WAVES) {
-            const uint2 r = seg[si];
-            const uint32_t h = tok[r.x];
-            if (h <= mid) {
-                const uint16_t v = tok[r.x + 1];
-                for (uint32_t k = lane; k < h && r.y + k < symcap; k += 64) sym[r.y + k] = v;
-            } else {
-                const uint32_t cnt = h - mid;
-                for (uint32_t k = lane; k < cnt && r.y + k < symcap; k += 64) {
-                    if (r.x + 1 + k < ntok) sym[r.y + k] = tok[r.x + 1 + k]; else bad = 1;
-                }
-            }
-        }
-        if (bad) s_misc[3] = 1;                                          // literal run past the end (Go: index panic)
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
-    if (nsym < 1) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
-    const uint32_t max_value = sym[0];                                  // deltarlecompressu16.go:71
+    // ---- phases 2+3, tile by tile: expansion, escape markers, pixel numbering ------------------------
+    if (nsym < 1 || nseg < 1) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+    const uint32_t seg0x = seg[0].x & 0x7FFFFFFFu;
+    if (seg0x >= ntok) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+    const uint32_t max_value = tok[seg0x];                          // first symbol of the stream (deltarlecompressu16.go:71)
     const int depth = mic_len16(max_value);
     if (depth == 0) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
     const uint32_t thr = (1u << (depth - 1)) - 1;
@@ -123,54 +111,153 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     uint16_t *px = u.px_out;
     uint32_t *flags = u.flags;
     if (tid == 0) u.dec_thr = thr;
-
-#ifdef MIC_STAMP
-    const uint64_t st2 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- phase 3: escape markers and pixel numbering -------------------------------------------
     {
-        uint32_t carry_marker = 0;       // marker state of the symbol before the tile
+        uint32_t carry_state = 0;        // marker state of the symbol in front of the tile
         uint32_t carry_px = 0;           // pixels numbered so far
-        for (uint32_t base = 1; base < nsym && carry_px < npx; base += PX_THREADS) {
-            const uint32_t i = base + tid;
-            const bool in = i < nsym;
-            const uint32_t x = in ? sym[i] : 0u;
-            const bool d = in && x == delim;
-            // f: state -> marker[i];  delim: swap (1,0) = 0b01 ; other: zero (0,0) = 0b00
-            uint32_t f = d ? 1u : 0u;
+        uint32_t s_lo = 0;               // first segment that reaches into the tile
+        for (uint32_t base = 0; base < nsym && carry_px < npx; base += PX_T) {
+            const uint32_t tile_end = min(base + PX_T, nsym);
+            // (a) every thread fetches its 8 consecutive symbols straight from the token stream.  The tile's
+            // segments (start symbol, payload position, run flag) are staged in LDS PX_THREADS at a time;
+            // a thread finds its segment by binary search and, when its 8 symbols lie inside one segment
+            // (the usual case: literal chunks are ~2^depth long), takes them with one 16-byte load.
+            const uint32_t i0 = base + tid * PX_SPT;
+            const uint32_t wend = min(i0 + PX_SPT, tile_end);            // this thread's symbols are [i0, wend)
+            uint32_t w8[4] = { 0u, 0u, 0u, 0u };
+            bool got = i0 >= tile_end;
+            for (uint32_t r0 = s_lo;; r0 += PX_THREADS - PX_SPT) {         // rounds overlap by 8 segments: a window spans at most 8
+                {
+                    const uint32_t si = r0 + tid;
+                    uint2 sg = make_uint2(0u, 0xFFFFFFFFu);
+                    if (si < nseg) sg = seg[si];
+                    s_segx[tid] = sg.x; s_segy[tid] = sg.y;
+                    if (tid == 0) { const uint32_t sj = r0 + PX_THREADS; s_segy[PX_THREADS] = (sj < nseg) ? seg[sj].y : 0xFFFFFFFFu; s_misc[4] = 0; }
+                }
+                __syncthreads();
+                if (s_segy[tid] < tile_end && s_segy[tid + 1] >= tile_end) s_misc[4] = tid + 1;   // sorted: one writer at most
+                __syncthreads();
+                const uint32_t cover_end = s_segy[PX_THREADS];           // first symbol this round's segments do not cover
+                const uint32_t cnt = (cover_end < tile_end) ? (uint32_t)PX_THREADS : s_misc[4];
+                if (!got && s_segy[0] <= i0 && wend <= cover_end) {
+                    uint32_t j = 0;
+                    for (uint32_t stp = (cnt > 1) ? (1u << (31 - __clz(cnt - 1))) : 0u; stp; stp >>= 1)
+                        if (s_segy[j + stp] <= i0) j += stp;
+                    uint32_t start = s_segy[j], endj = min(s_segy[j + 1], nsym), sx = s_segx[j];
+                    uint32_t bad = 0;
+                    if (wend - i0 == PX_SPT && i0 + PX_SPT <= endj) {
+                        const uint32_t xs = sx & 0x7FFFFFFFu;
+                        if (sx >> 31) {                                   // same-run: one value
+                            const uint32_t v = tok[xs];
+                            w8[0] = w8[1] = w8[2] = w8[3] = v | (v << 16);
+                        } else {
+                            const uint32_t src = xs + (i0 - start);
+                            if (src + PX_SPT <= ntok) {
+                                const PxVec v = *(const PxVec *)(tok + src);
+#pragma unroll
+                                for (int k = 0; k < PX_SPT; k++) w8[k >> 1] |= (uint32_t)v.v[k] << (16 * (k & 1));
+                            } else bad = 1;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PX_SPT; k++) {
+                            const uint32_t i = i0 + k;
+                            if (i < wend) {
+                                while (i >= endj) { j++; start = s_segy[j]; endj = min(s_segy[j + 1], nsym); sx = s_segx[j]; }
+                                const uint32_t xs = sx & 0x7FFFFFFFu;
+                                const uint32_t src = (sx >> 31) ? xs : xs + (i - start);
+                                if (src < ntok) w8[k >> 1] |= (uint32_t)tok[src] << (16 * (k & 1)); else bad = 1;
+                            }
+                        }
+                    }
+                    if (bad) s_misc[3] = 1;                              // literal run past the end (Go: index panic)
+                    if (wend == tile_end) s_misc[5] = r0 + j;            // segment of the tile's last symbol: where the next tile starts
+                    got = true;
+                }
+                const bool more = cover_end < tile_end;
+                __syncthreads();
+                if (!more) break;
+            }
+            s_lo = s_misc[5];
+            if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+            // (b) marker[i] = isDelim[i] & !marker[i-1], a pixel = a non-marker symbol.
+            // One scan carries, for both possible entry states, the exit state and the pixel count:
+            //   t = s0 | s1 << 1 | c0 << 2 | c1 << 16
+            uint32_t dmask = 0, vmask = 0;                               // bit k: symbol k is a delimiter / is inside the stream
+#pragma unroll
+            for (int k = 0; k < PX_SPT; k++) {
+                const uint32_t x = (w8[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t i = i0 + k;
+                const bool in = i < tile_end && i != 0;                  // symbol 0 is the max value, not a pixel
+                if (in) vmask |= 1u << k;
+                if (in && x == delim) dmask |= 1u << k;
+            }
+            uint32_t tr;
+            {
+                uint32_t s0 = 0, s1 = 1, c0 = 0, c1 = 0;
+#pragma unroll
+                for (int k = 0; k < PX_SPT; k++) {
+                    const uint32_t d = (dmask >> k) & 1u, v = (vmask >> k) & 1u;
+                    const uint32_t m0 = d & (s0 ^ 1u), m1 = d & (s1 ^ 1u);
+                    c0 += v & (m0 ^ 1u); c1 += v & (m1 ^ 1u);
+                    s0 = m0; s1 = m1;
+                }
+                tr = s0 | (s1 << 1) | (c0 << 2) | (c1 << 16);
+            }
+            auto compose = [](uint32_t a, uint32_t b) -> uint32_t {     // a then b
+                const uint32_t a0 = a & 1u, a1 = (a >> 1) & 1u;
+                const uint32_t bc0 = (b >> 2) & 0x3FFFu, bc1 = b >> 16;
+                const uint32_t n0 = (b >> a0) & 1u, n1 = (b >> a1) & 1u;
+                const uint32_t c0 = ((a >> 2) & 0x3FFFu) + (a0 ? bc1 : bc0);
+                const uint32_t c1 = (a >> 16) + (a1 ? bc1 : bc0);
+                return n0 | (n1 << 1) | (c0 << 2) | (c1 << 16);
+            };
+            uint32_t incl = tr;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
-                uint32_t o = __shfl_up(f, dd);
-                if (lane >= (uint32_t)dd) f = fn_compose(f, o);
+                const uint32_t o = __shfl_up(incl, dd);
+                if (lane >= (uint32_t)dd) incl = compose(o, incl);
             }
-            if (lane == 63) s_fn[wave] = f;
+            if (lane == 63) s_fn[wave] = incl;
+            uint32_t excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 2u;                                    // identity: s0 = 0, s1 = 1, no pixels
             __syncthreads();
-            uint32_t st_in = carry_marker;
-            for (uint32_t wv = 0; wv < wave; wv++) st_in = (s_fn[wv] >> st_in) & 1;
-            const uint32_t marker = (f >> st_in) & 1;
-            const uint32_t prev_marker = __shfl_up(marker, 1);
-            // marker of the previous symbol: previous lane, or the state entering this wave
-            const uint32_t raw = (lane == 0) ? st_in : prev_marker;
-            // tile-wide exclusive count of pixels (non-marker symbols)
-            const uint32_t is_px = (in && !marker) ? 1u : 0u;
-            const uint32_t incl = wave_incl_add(is_px, lane);
-            if (lane == 63) s_scan[wave] = incl;
-            uint32_t last_marker_tile = 0;
+            // entry (state, pixel count) of this wave and exit of the tile, from the 16 wave totals
+            uint32_t st_w = carry_state, cnt_w = 0, st_all, cnt_all;
+            {
+                uint32_t stt = carry_state, cc = 0;
+                for (uint32_t wv = 0; wv < PX_WAVES; wv++) {
+                    if (wv == wave) { st_w = stt; cnt_w = cc; }
+                    const uint32_t f = s_fn[wv];
+                    cc += stt ? (f >> 16) : ((f >> 2) & 0x3FFFu);
+                    stt = (f >> stt) & 1u;
+                }
+                st_all = stt; cnt_all = cc;
+            }
+            uint32_t st_in = (excl >> st_w) & 1u;
+            uint32_t pl = cnt_w + (st_w ? (excl >> 16) : ((excl >> 2) & 0x3FFFu));    // tile-local pixel index
+#pragma unroll
+            for (int k = 0; k < PX_SPT; k++) {
+                const uint32_t x = (w8[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t d = (dmask >> k) & 1u, v = (vmask >> k) & 1u;
+                const uint32_t m = d & (st_in ^ 1u);
+                if (v && !m) {
+                    s_px[pl] = (uint16_t)x;
+                    const uint32_t pg = carry_px + pl;
+                    if (st_in && pg < npx) atomicOr(&flags[pg >> 5], 1u << (pg & 31));   // stored raw behind an escape
+                    pl++;
+                }
+                st_in = m;
+            }
             __syncthreads();
-            uint32_t woff = 0, total = 0;
-            for (uint32_t wv = 0; wv < PX_WAVES; wv++) { uint32_t v = s_scan[wv]; if (wv < wave) woff += v; total += v; }
-            {   // marker state leaving the tile = compose all waves
-                uint32_t stt = carry_marker;
-                for (uint32_t wv = 0; wv < PX_WAVES; wv++) stt = (s_fn[wv] >> stt) & 1;
-                last_marker_tile = stt;
+            // (c) the tile's pixels leave as 16-byte vectors (2-byte aligned destination)
+            {
+                const uint32_t n_out = min(cnt_all, npx - carry_px);
+                const uint32_t o = tid * PX_SPT;
+                if (o + PX_SPT <= n_out) *(PxVec *)(px + carry_px + o) = *(const PxVec *)(s_px + o);
+                else for (uint32_t k = o; k < n_out; k++) px[carry_px + k] = s_px[k];
             }
-            const uint32_t p = carry_px + woff + incl - is_px;
-            if (is_px && p < npx) {
-                px[p] = (uint16_t)x;
-                if (raw) atomicOr(&flags[p >> 5], 1u << (p & 31));
-            }
-            carry_px += total;
-            carry_marker = last_marker_tile;
+            carry_px += cnt_all;
+            carry_state = st_all;
             __syncthreads();
         }
         if (carry_px < npx) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }   // tokens ran out (Go: panic)

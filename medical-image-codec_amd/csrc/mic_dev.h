@@ -46,13 +46,14 @@ struct MicUnit {
     int32_t  *cumul;          // [65538]
     uint8_t  *blob;           // encode: staging output (NCount + bitstream, 6-byte prefix first)
     uint32_t  blob_cap;
-    uint2    *seg;            // decode: RLE segments {token index of the header, first symbol index}
+    uint2    *seg;            // decode: RLE segments {token index of the payload | same-run << 31, first symbol index}
     uint32_t  seg_cap;
     uint16_t *sym;            // decode: expanded delta-symbol stream; encode: per-token tANS states
     uint32_t  sym_cap;
     uint32_t *flags;          // decode: 1 bit per pixel, set = pixel stored raw behind an escape
     uint32_t  nseg;
     uint32_t  nsym;
+    uint32_t  walk_ok;        // decode: seg/nseg/nsym already produced by the tANS kernel's header walker
     uint32_t  dec_thr;        // decode: delta threshold (1 << (depth-1)) - 1 of the stream's own max value
     // ---- results -----------------------------------------------------------------
     uint32_t ntok;            // number of u16 in tok
