@@ -587,6 +587,7 @@ int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) {
     out8[0] = u.ntok; out8[1] = u.blob_len; out8[2] = u.table_log; out8[3] = u.symbol_len;
     out8[4] = u.max_count; out8[5] = u.hdr_len; out8[6] = u.zero_bits; out8[7] = u.flavour;
     out8[8] = u.count; out8[9] = u.bits_off; out8[10] = (uint32_t)u.nstates_used; out8[11] = (uint32_t)u.status; out8[12] = u.nseg; out8[13] = u.nsym; out8[14] = u.seg_cap;
+    for (int k = 0; k < 16; k++) out8[16 + k] = u.dbg[k];
     return MIC_OK;
 }
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {

@@ -62,9 +62,6 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     const uint32_t symcap = min(u.sym_cap, 2u * npx + 2u);
     uint2 *seg = u.seg;
 
-#ifdef MIC_STAMP
-    const uint64_t st0 = __builtin_amdgcn_s_memtime();
-#endif
     // ---- phase 1: header walk (wave 0) -----------------------------------------------------
     if (u.walk_ok) {                                                    // k_dec_tans_lds walked the headers as it produced them
         if (tid == 0) { s_misc[0] = u.nseg; s_misc[1] = u.nsym; s_misc[2] = 0; s_misc[3] = 0; }
@@ -95,10 +92,6 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     const uint32_t nseg = s_misc[0], nsym = s_misc[1];
     if (s_misc[2]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
 
-#ifdef MIC_STAMP
-    const uint64_t st1 = __builtin_amdgcn_s_memtime();
-    const uint64_t st2 = st1;
-#endif
     // ---- phases 2+3, tile by tile: expansion, escape markers, pixel numbering ------------------------
     if (nsym < 1 || nseg < 1) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
     const uint32_t seg0x = seg[0].x & 0x7FFFFFFFu;
@@ -265,9 +258,6 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
     __threadfence_block();
     __syncthreads();
 
-#ifdef MIC_STAMP
-    const uint64_t st3 = __builtin_amdgcn_s_memtime();
-#endif
     // ---- phase 4: inverse predictor, skewed wavefront ---------------------------------------------
     // Thread r owns row r of the band and works on the 8-pixel column group t - r at step t: its top
     // neighbours were produced by thread r-1 one step earlier (LDS hand-off, one barrier per step, 8
@@ -338,13 +328,6 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
         __threadfence_block();
         __syncthreads();
     }
-#ifdef MIC_STAMP
-    if (tid == 0) {
-        const uint64_t st4 = __builtin_amdgcn_s_memtime();
-        u.max_count = (uint32_t)(st1 - st0); u.hdr_len = (uint32_t)(st2 - st1); u.zero_bits = (uint32_t)(st3 - st2); u.flavour = (uint32_t)(st4 - st3);
-        u.nseg = nseg; u.nsym = nsym;
-    }
-#endif
 }
 
 

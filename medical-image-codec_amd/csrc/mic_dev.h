@@ -68,7 +68,17 @@ struct MicUnit {
     uint32_t bits_off;        // decode: offset of the bitstream inside comp_in
     uint32_t count;           // decode: symbol count from the 6-byte prefix
     uint32_t flavour;         // decode: 1/2/4/8, 108 = rANS-8
+    uint32_t dbg[16];         // MIC_STAMP builds: shader-clock ticks per kernel phase (tools/stamp_*.py)
 };
+
+// Phase stamps for diagnostic builds (EXTRA_FLAGS=-DMIC_STAMP); they compile to nothing otherwise.
+#ifdef MIC_STAMP
+#define MIC_STAMP_BEGIN() uint64_t _mic_t0 = __builtin_amdgcn_s_memtime()
+#define MIC_STAMP_AT(u, k) do { const uint64_t _t = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) (u).dbg[k] += (uint32_t)(_t - _mic_t0); _mic_t0 = _t; } while (0)
+#else
+#define MIC_STAMP_BEGIN() do { } while (0)
+#define MIC_STAMP_AT(u, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int mic_len16(uint32_t v) { return v ? 32 - __clz(v) : 0; }
 // fseu16.go:170-172 -- Len32(v)-1, wraps to 0xFFFFFFFF for 0

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         }
     }
     __syncthreads();
+    MIC_STAMP_BEGIN();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
         // ---- A: delta symbols of this tile's pixels (deltarlecompressu16.go:31-61) ----------
@@ -240,6 +241,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         }
         __syncthreads();
         const uint32_t g1 = g0 + n;
+        MIC_STAMP_AT(u, 0);
         // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3]
         const uint32_t nwin = flush ? 3u : n;
         // ---- B: per-position facts + per-thread run / stretch starts --------------------------
@@ -303,6 +305,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             run_tot = max(run_tot, a); str_tot = max(str_tot, b);
         }
         run_in = max(run_in, run1); str_in = max(str_in, str1);
+        MIC_STAMP_AT(u, 1);
         // ---- C: tokens owned by each position ---------------------------------------------------
         uint32_t tc[TK_SPT]; uint32_t kk[TK_SPT]; uint32_t tsum = 0;
         {
@@ -342,6 +345,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         uint32_t toff = 0, ttot = 0;
 #pragma unroll
         for (int wv = 0; wv < TK_WAVES; wv++) { const uint32_t v = s_tc[wv]; if ((uint32_t)wv < wave) toff += v; ttot += v; }
+        MIC_STAMP_AT(u, 2);
         // ---- D: write ----------------------------------------------------------------------------
         {
             uint32_t pos = outp + toff + tincl - tsum;
@@ -393,6 +397,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             }
             if (ovf) s_ovf = 1;
         }
+        MIC_STAMP_AT(u, 3);
         // ---- E: carry --------------------------------------------------------------------------------
         outp += ttot;
         run1 = run_tot; str1 = str_tot;
@@ -411,6 +416,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             __syncthreads();
         }
         g0 = g1;
+        MIC_STAMP_AT(u, 4);
     }
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
@@ -613,6 +619,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_THREADS 1024
 #define TE_WAVES 16
 #define TE_BLK 32                 // tokens per 64-byte block
+#define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
 
 // One block of 32 tokens / 32 recorded states as four 16-byte vectors.
 struct TeBlk { uint4 v[4]; };
@@ -637,12 +644,15 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 
 // Thread t (t = 0 encodes first) owns the 32-token blocks [b_lo, b_hi); all N chains of those
 // tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
-template <int N, bool RANS>
-__device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
+// TTL: the per-symbol records (symbolTT / rANS freq+bias) were copied to LDS (alphabets up to TE_TT_SYMS);
+// otherwise every coding step gathers them from HBM.
+template <int N, bool RANS, bool TTL>
+__device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, const int32_t *s_ttfind,
+                          uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
     const uint16_t *src = u.tok;
-    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
+    const uint32_t *tt_nb = TTL ? s_ttnb : u.tt_nb; const int32_t *tt_find = TTL ? s_ttfind : u.tt_find;
     uint16_t *stv = u.sym;
     const uint32_t hdr_len = u.hdr_len;
     uint8_t *bits_base = u.blob + 6 + hdr_len;
@@ -674,6 +684,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
         if (RANS) { const uint32_t e = tt_nb[sy], freq = e & 0xFFFFF, k0 = e >> 20; return k0 - ((state < (freq << k0)) ? 1u : 0u); }
         return (state + tt_nb[sy]) >> 16;
     };
+    MIC_STAMP_BEGIN();
     uint32_t st[N];
 #pragma unroll
     for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
@@ -699,6 +710,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
     uint32_t assumed[N];
 #pragma unroll
     for (int k = 0; k < N; k++) assumed[k] = size;
+    MIC_STAMP_AT(u, 8);
     // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
     for (uint32_t round = 0; round < TE_THREADS; round++) {
         __syncthreads();
@@ -758,6 +770,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
     }
     __threadfence_block();
     __syncthreads();
+    MIC_STAMP_AT(u, 9);
     // ---- 3. bit offsets ---------------------------------------------------------------------------
     uint32_t mybits = 0;
     for (uint32_t b = b_hi; b > b_lo; b--) {
@@ -789,6 +802,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
     total_bytes_out = s_scan[TE_WAVES + 1];
     rc_out = rc;
     if (rc != MICD_OK) return;
+    MIC_STAMP_AT(u, 10);
     // ---- 4. pack -------------------------------------------------------------------------------------
     const uint32_t first_w = (uint32_t)(gstart >> 5);
     const bool own_first = (gstart & 31) == 0;
@@ -837,6 +851,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, uint16_t (*s_E)[8], uint
         }
         words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
     }
+    MIC_STAMP_AT(u, 11);
 }
 
 template <int TLHI>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI)
@@ -854,6 +869,10 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units) {
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
     if (u.nstates != 108) for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
+    uint32_t *s_ttnb = (uint32_t *)(s_stab + (1u << TLHI));
+    int32_t *s_ttfind = (int32_t *)(s_ttnb + TE_TT_SYMS);
+    const bool ttl = TLHI <= 15 && u.symbol_len <= TE_TT_SYMS;
+    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += TE_THREADS) { s_ttnb[i] = u.tt_nb[i]; s_ttfind[i] = u.tt_find[i]; }
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
     const bool rans = u.nstates == 108;                                          // rans8state.go: 8 lanes, magic FF 08
@@ -865,11 +884,19 @@ __global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units) {
         else if (n <= 2 && lanes <= 2) rc = MICD_ERR_INTERNAL;                   // "src too small"
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
-            if (rans) te_encode<8, true>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else if (lanes == 8) te_encode<8, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else if (lanes == 4) te_encode<4, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else if (lanes == 2) te_encode<2, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
-            else te_encode<1, false>(u, s_stab, s_E, s_scan, rc, total_bytes);
+            if (TLHI <= 15 && ttl) {
+                if (rans) te_encode<8, true, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+            } else {
+                if (rans) te_encode<8, true, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+            }
         }
         __syncthreads();
         if (rc == MICD_OK) {
@@ -961,10 +988,10 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
             attr_done = true;
         }
         if (t) t->mark("k_enc_tans_wg<13>");
-        hipLaunchKernelGGL(k_enc_tans_wg<13>, dim3(n), dim3(TE_THREADS), 2u << 13, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tans_wg<13>, dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
         if (t) t->mark("k_enc_tans_wg<other classes>");
-        hipLaunchKernelGGL(k_enc_tans_wg<14>, dim3(n), dim3(TE_THREADS), 2u << 14, stream, d_units);
-        hipLaunchKernelGGL(k_enc_tans_wg<15>, dim3(n), dim3(TE_THREADS), 2u << 15, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tans_wg<14>, dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
+        hipLaunchKernelGGL(k_enc_tans_wg<15>, dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
         hipLaunchKernelGGL(k_enc_tans_wg<16>, dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
     }
     if (t) t->mark("k_enc_tans_serial");

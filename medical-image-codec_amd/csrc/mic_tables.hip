@@ -46,6 +46,7 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t size = 1u << tl;
     const uint32_t *hist = u.hist;
+    MIC_STAMP_BEGIN();
     // ---- normalise, primary method (fsecompressu16.go:524-571), one symbol per thread -----------
     {
         const uint64_t scale = 62 - (uint64_t)tl;
@@ -97,17 +98,104 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
             s_misc[2] = second; s_misc[3] = (uint32_t)rc;
         }
         __syncthreads();
-        if (s_misc[2]) {                                    // rare: serial secondary method on the HBM arrays
-            if (tid == 0) s_misc[3] = (uint32_t)mic_normalize_count2(u.hist, u.norm, symbol_len, n, tl);
-            __threadfence_block();
-            __syncthreads();
-            if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
-            if ((void *)norm != (void *)u.norm)
-                for (uint32_t s = tid; s < symbol_len; s += TP_THREADS) norm[s] = (NormT)u.norm[s];
+        if (s_misc[2]) {
+            // normalizeCount2 (fsecompressu16.go:573-651).  Common for alphabets close to the table size
+            // (12-bit frames at tableLog 13), so it runs on the whole group: two classification passes with
+            // block reductions, then the weights  (end >> v) - (start >> v)  where `end` is a running sum of
+            // count * rStep over the undecided symbols -- an exclusive 64-bit prefix sum.  The two corner
+            // cases that turn on a serial loop in the reference stay serial (tid 0, HBM arrays).
+            const int32_t not_yet = -2;
+            uint64_t *s_t64 = (uint64_t *)(s_tmp + 32);                  // 16 wave partials + spare, 8-byte aligned
+            auto reduce2 = [&](uint32_t a, uint64_t b, uint32_t &ra, uint64_t &rb) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { a += (uint32_t)__shfl_xor((int)a, d); b += (uint64_t)__shfl_xor((long long)b, d); }
+                __syncthreads();
+                if (lane == 0) { s_tmp[wave] = a; s_t64[wave] = b; }
+                __syncthreads();
+                uint32_t ta = 0; uint64_t tb = 0;
+                for (int w = 0; w < TP_WAVES; w++) { ta += s_tmp[w]; tb += s_t64[w]; }
+                ra = ta; rb = tb;
+            };
+            uint32_t total = n;
+            const uint32_t low_threshold2 = total >> tl;
+            uint32_t low_one = (total * 3) >> (tl + 1);
+            uint32_t d1 = 0; uint64_t sub1 = 0;
+            for (uint32_t s2 = tid; s2 < symbol_len; s2 += TP_THREADS) {
+                const uint32_t cnt = hist[s2];
+                int32_t nv;
+                if (cnt == 0) nv = 0;
+                else if (cnt <= low_threshold2) { nv = -1; d1++; sub1 += cnt; }
+                else if (cnt <= low_one) { nv = 1; d1++; sub1 += cnt; }
+                else nv = not_yet;
+                norm[s2] = (NormT)nv;
+            }
+            uint32_t distributed; uint64_t subs;
+            reduce2(d1, sub1, distributed, subs);
+            total -= (uint32_t)subs;
+            int rc2 = MICD_OK;
+            bool serial = false;
+            uint32_t to_distribute = 0;
+            if (distributed >= size) rc2 = MICD_ERR_INTERNAL;            // the reference divides by zero or spins (see mic_normalize_count2)
+            else {
+                to_distribute = size - distributed;
+                if ((total / to_distribute) > low_one) {                 // uniform
+                    low_one = (total * 3) / (to_distribute * 2);
+                    uint32_t d2 = 0; uint64_t sub2 = 0;
+                    for (uint32_t s2 = tid; s2 < symbol_len; s2 += TP_THREADS) {
+                        const uint32_t cnt = hist[s2];
+                        if ((int32_t)norm[s2] == not_yet && cnt <= low_one) { norm[s2] = (NormT)1; d2++; sub2 += cnt; }
+                    }
+                    uint32_t dd; uint64_t ss;
+                    reduce2(d2, sub2, dd, ss);
+                    distributed += dd; total -= (uint32_t)ss;
+                    if (distributed >= size) rc2 = MICD_ERR_INTERNAL;
+                    else to_distribute = size - distributed;
+                }
+                if (rc2 == MICD_OK && (distributed == symbol_len + 1 || total == 0)) serial = true;
+            }
+            if (rc2 == MICD_OK && !serial) {
+                const uint64_t v_step_log = 62 - (uint64_t)tl;
+                const uint64_t midv = (1ull << (v_step_log - 1)) - 1;
+                const uint64_t r_step = (((1ull << v_step_log) * (uint64_t)to_distribute) + midv) / (uint64_t)total;
+                uint64_t carry = midv;
+                uint32_t badw = 0;
+                for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
+                    const uint32_t s2 = base + tid;
+                    const bool ny = s2 < symbol_len && (int32_t)norm[s2] == not_yet;
+                    const uint64_t val = ny ? (uint64_t)hist[s2] * r_step : 0ull;
+                    uint64_t incl = val;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = (uint64_t)__shfl_up((long long)incl, d); if (lane >= (uint32_t)d) incl += o; }
+                    __syncthreads();
+                    if (lane == 63) s_t64[wave] = incl;
+                    __syncthreads();
+                    uint64_t off = 0, tot = 0;
+                    for (int w = 0; w < TP_WAVES; w++) { const uint64_t x = s_t64[w]; if ((uint32_t)w < wave) off += x; tot += x; }
+                    if (ny) {
+                        const uint64_t start = carry + off + incl - val, end = start + val;
+                        const uint32_t weight = (uint32_t)(end >> v_step_log) - (uint32_t)(start >> v_step_log);
+                        if (weight < 1) badw = 1;
+                        norm[s2] = (NormT)(int32_t)weight;
+                    }
+                    carry += tot;
+                }
+                if (__syncthreads_or((int)badw)) rc2 = MICD_ERR_INTERNAL;
+            }
+            if (rc2 == MICD_OK && serial) {
+                __syncthreads();
+                if (tid == 0) s_misc[3] = (uint32_t)mic_normalize_count2(u.hist, u.norm, symbol_len, n, tl);
+                __threadfence_block();
+                __syncthreads();
+                rc2 = (int)s_misc[3];
+                if (rc2 == MICD_OK && (void *)norm != (void *)u.norm)
+                    for (uint32_t s2 = tid; s2 < symbol_len; s2 += TP_THREADS) norm[s2] = (NormT)u.norm[s2];
+            }
+            if (rc2 != MICD_OK) { if (tid == 0) u.status = rc2; return; }
         }
     }
     __threadfence_block();
     __syncthreads();
+    MIC_STAMP_AT(u, 5);
     // ---- NCount header (one lane; fsecompressu16.go:191-289) ----------------------------------------
     if (tid == 0) {
         int rc = MICD_OK;
@@ -122,6 +210,7 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     }
     __syncthreads();
     if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
+    MIC_STAMP_AT(u, 6);
     if (u.nstates == 108) {
         // buildRansEncTable (ransu16.go:139-180): bias = cumulative frequency, positives in symbol order, then the
         // low-probability symbols; record = freq | k0 << 20 in tt_nb, bias in tt_find.  No state table.
@@ -173,6 +262,7 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     }
     if (__syncthreads_or((int)zb)) { if (tid == 0) u.zero_bits = 1; }
     else if (tid == 0) u.zero_bits = 0;
+    MIC_STAMP_AT(u, 7);
 }
 
 __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
