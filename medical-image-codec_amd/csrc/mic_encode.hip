@@ -128,14 +128,18 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 //     header midCount + chunk length in front; a chunk boundary needs two more symbols behind
 //     it (they sit in the reference's buffer when the flush fires), so the last two symbols of
 //     the whole stream never open a chunk.
-// Every symbol can therefore compute the tokens it is responsible for from x[i-2..i+3], its
+// Every symbol can therefore compute the tokens it is responsible for from x[i-3..i+3], its
 // index inside its run / stretch (segmented max-scans) and a prefix sum of token counts.
-// Symbols are produced 2048 pixels at a time (1 or 2 symbols per pixel, prefix-summed) into an
-// LDS window and tokenised with a delay of 3 symbols so the look-ahead is always present.
+// A tile is 4096 pixels: their symbols (1 or 2 per pixel, prefix-summed only when the tile holds
+// an escape) go into an LDS window and are tokenised with a delay of 3 symbols so the look-ahead
+// is always present.  A thread owns 8 consecutive window positions; the equality pattern of its
+// 14-symbol neighbourhood is one bit mask and "in a same-run", "run start", "stretch start",
+// "run end" are shifts and ANDs of it; run / stretch indices modulo c advance incrementally from
+// one multiply-high reduction per thread and tile.
 #define TK_THREADS 1024
 #define TK_WAVES 16
-#define TK_PPT 2
-#define TK_SPT 4
+#define TK_PPT 4
+#define TK_SPT 8
 #define TK_WIN (TK_THREADS * TK_SPT)
 #define TK_HWIN 16384
 
@@ -149,6 +153,26 @@ __device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t lane) 
     for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v = max(v, o); }
     return v;
 }
+// 16 per-wave partials in LDS -> this wave's exclusive prefix and the group total (add / max)
+__device__ __forceinline__ void tk_block16_add(const uint32_t *s, uint32_t wave, uint32_t &excl, uint32_t &total) {
+    const uint4 a = ((const uint4 *)s)[0], b = ((const uint4 *)s)[1], c = ((const uint4 *)s)[2], d = ((const uint4 *)s)[3];
+    const uint32_t v[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    uint32_t e = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { e += ((uint32_t)w < wave) ? v[w] : 0u; t += v[w]; }
+    excl = e; total = t;
+}
+__device__ __forceinline__ void tk_block16_max(const uint32_t *s, uint32_t wave, uint32_t &excl, uint32_t &total) {
+    const uint4 a = ((const uint4 *)s)[0], b = ((const uint4 *)s)[1], c = ((const uint4 *)s)[2], d = ((const uint4 *)s)[3];
+    const uint32_t v[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    uint32_t e = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { e = max(e, ((uint32_t)w < wave) ? v[w] : 0u); t = max(t, v[w]); }
+    excl = e; total = t;
+}
+
+typedef uint32_t tk_v2 __attribute__((ext_vector_type(2)));
+typedef tk_v2 TkD __attribute__((aligned(2)));                 // 4 pixels, 2-byte aligned
 
 // SRC 0: frame units (mode 0) -- symbols are the Delta(avg) residuals of the pixels, stream = [delim][RLE(maxValue, symbols)].
 // SRC 1: RLE-of-symbols units (mode 2, wavelet / residual paths) -- RleCompressU16.Init(len,1,max).Compress(symbols)
@@ -156,29 +180,35 @@ __device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t lane) 
 template <int SRC>
 __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    __shared__ uint16_t xs[TK_WIN + 16];          // [0..5] = 6 symbols before the tile, [6..] = new symbols
-    __shared__ uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
-    __shared__ uint32_t s_ovf;
+    __shared__ __attribute__((aligned(16))) uint16_t xs[TK_WIN + 16];   // [0..5] = 6 symbols before the tile, [6..] = new symbols
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
+    __shared__ uint32_t s_ovf, s_last;
     // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
     if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
-    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; }
+    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last = 0; }
     const int depth = mic_len16(u.max_value);
     if (!SRC && (u.w <= 0 || u.h <= 0)) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
     if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
     const uint32_t thr = (1u << (depth - 1)) - 1;
     const uint32_t delim = (1u << depth) - 1;
     const uint32_t mid = (1u << (depth - 1)) - 1;          // Len16(delim) == depth
-    const uint32_t c = mid - 3;
+    const uint32_t c = mid - 3;                            // >= 4
+    const uint32_t cmagic = (uint32_t)(0x100000000ull / c);
+    auto mod_c = [&](uint32_t a) -> uint32_t {             // a % c: the multiply-high quotient is at most 1 short
+        const uint32_t r = a - __umulhi(a, cmagic) * c;
+        return r >= c ? r - c : r;
+    };
     const uint16_t *in = SRC ? (const uint16_t *)u.sym : u.px_in;
     uint16_t *tok = u.tok;
     const uint32_t cap = u.tok_cap;
     const uint32_t W = SRC ? 1u : (uint32_t)u.w;
     const uint32_t npx = SRC ? u.nsym : W * (uint32_t)u.h;
-    const uint32_t ntiles = (npx + TK_THREADS * TK_PPT - 1) / (TK_THREADS * TK_PPT);
+    constexpr uint32_t TP = TK_THREADS * TK_PPT;
+    const uint32_t ntiles = (npx + TP - 1) / TP;
     // carried, work-group uniform state
     uint32_t g0 = SRC ? 0u : 1u;     // symbols generated so far; frames: symbol 0 = maxValue is pre-seeded in the halo
     uint32_t outp = SRC ? 3u : 1u;   // tokens written so far; tok[0] = delimiter / max (rlecompressu16.go:21) [+ length words]
@@ -187,6 +217,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
     uint32_t *ghist = u.hist;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
+    for (uint32_t i = tid; i < TK_WIN + 16; i += TK_THREADS) xs[i] = 0;
     __syncthreads();
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
@@ -208,175 +239,193 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
         // ---- A: delta symbols of this tile's pixels (deltarlecompressu16.go:31-61) ----------
-        uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0;
-        if (!flush) {
-            const uint32_t gbase = tile * (TK_THREADS * TK_PPT) + tid * TK_PPT;
+        uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0; int esc = 0;
+        const uint32_t gbase = tile * TP + tid * TK_PPT;
+        if (!flush && gbase < npx) {
+            if (SRC) {
 #pragma unroll
-            for (int k = 0; k < TK_PPT; k++) {
-                const uint32_t g = gbase + k;
-                if (SRC) { if (g < npx) ls[cnt++] = in[g]; continue; }
-                if (g < npx) {
-                    const uint32_t y = g / W, x = g - y * W;
-                    int32_t prev = 0;
-                    if (x > 0) prev = in[g - 1];
-                    if (y > 0) prev += in[g - W];
-                    if (x > 0 && y > 0) prev >>= 1;
-                    const uint32_t val = in[g];
+                for (int k = 0; k < TK_PPT; k++) if (gbase + k < npx) ls[cnt++] = in[gbase + k];
+            } else {
+                const uint32_t y = gbase / W, x = gbase - y * W;
+                uint32_t cur[TK_PPT], top[TK_PPT], lft = 0;
+                const bool row4 = x + TK_PPT <= W && gbase + TK_PPT <= npx;     // the 4 pixels share a row
+                if (row4) {
+                    const tk_v2 cv = *(const TkD *)(in + gbase);
+                    cur[0] = cv.x & 0xFFFFu; cur[1] = cv.x >> 16; cur[2] = cv.y & 0xFFFFu; cur[3] = cv.y >> 16;
+                    if (y > 0) {
+                        const tk_v2 tv = *(const TkD *)(in + gbase - W);
+                        top[0] = tv.x & 0xFFFFu; top[1] = tv.x >> 16; top[2] = tv.y & 0xFFFFu; top[3] = tv.y >> 16;
+                    } else top[0] = top[1] = top[2] = top[3] = 0;
+                    if (x > 0) lft = in[gbase - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < TK_PPT; k++) {
+                    const uint32_t g = gbase + k;
+                    if (g >= npx) break;
+                    uint32_t val; int32_t prev;
+                    if (row4) {
+                        val = cur[k];
+                        const uint32_t l = k ? cur[k - 1] : lft;
+                        if (x + k > 0 && y > 0) prev = (int32_t)((l + top[k]) >> 1);
+                        else if (x + k > 0) prev = (int32_t)l;
+                        else prev = (int32_t)top[k];                        // 0 on row 0
+                    } else {
+                        const uint32_t yy = g / W, xx = g - yy * W;
+                        prev = 0;
+                        if (xx > 0) prev = in[g - 1];
+                        if (yy > 0) prev += in[g - W];
+                        if (xx > 0 && yy > 0) prev >>= 1;
+                        val = in[g];
+                    }
                     const int32_t diff = (int32_t)val - prev;
                     const uint32_t ad = (uint32_t)(diff < 0 ? -diff : diff) & 0xFFFF;
-                    if (ad >= thr) { ls[cnt++] = delim; ls[cnt++] = val; }
+                    if (ad >= thr) { ls[cnt++] = delim; ls[cnt++] = val; esc = 1; }
                     else ls[cnt++] = (uint32_t)((int32_t)thr + diff) & 0xFFFF;
                 }
             }
         }
-        const uint32_t incl = tk_wave_incl_add(cnt, lane);
-        if (lane == 63) s_cnt[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, n = 0;
-#pragma unroll
-        for (int wv = 0; wv < TK_WAVES; wv++) { const uint32_t v = s_cnt[wv]; if ((uint32_t)wv < wave) woff += v; n += v; }
-        {
-            const uint32_t off = 6 + woff + incl - cnt;
-            for (uint32_t k = 0; k < cnt; k++) xs[off + k] = (uint16_t)ls[k];
+        uint32_t off, n;
+        if (__syncthreads_or(esc)) {                            // rare: an escape doubles its pixel, offsets need a scan
+            const uint32_t incl = tk_wave_incl_add(cnt, lane);
+            if (lane == 63) s_cnt[wave] = incl;
+            __syncthreads();
+            uint32_t woff;
+            tk_block16_add(s_cnt, wave, woff, n);
+            off = woff + incl - cnt;
+        } else {
+            off = tid * TK_PPT;
+            n = flush ? 0u : min(TP, npx - tile * TP);
         }
+#pragma unroll
+        for (int k = 0; k < 2 * TK_PPT; k++) if ((uint32_t)k < cnt) xs[6 + off + k] = (uint16_t)ls[k];
         __syncthreads();
         const uint32_t g1 = g0 + n;
         MIC_STAMP_AT(u, 0);
-        // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3]
+        // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3];  i3 = i + 3 = g0 + p keeps the arithmetic unsigned
         const uint32_t nwin = flush ? 3u : n;
-        // ---- B: per-position facts + per-thread run / stretch starts --------------------------
-        uint32_t my_run = 0, my_str = 0;            // latest start (index+1) inside this thread's positions
-        uint32_t same_bits = 0;                     // bit q = isSame, bit 8+q = run start, 16+q = stretch start
-        uint32_t prev_same_in = 0;                  // isSame of the symbol before this thread's first position
+        const uint32_t p0 = tid * TK_SPT;
+        // ---- B: equality pattern of the thread's neighbourhood x[i0-3 .. i0+10] -----------------
+        uint32_t v[14];
         {
-            // isSame of position p-1 for the thread's first position: recompute from the window
-            // (needs x[i-3], present for p >= 1 because the halo holds 3 already-processed symbols)
-            const uint32_t p0 = tid * TK_SPT;
-            if (p0 == 0) prev_same_in = last_same;
-            else if (p0 <= nwin) {
-                const int64_t i = (int64_t)g0 - 3 + p0 - 1;          // symbol before the first position
-                if (i >= 0) {
-                    const uint32_t idx = p0 - 1 + 3;
-                    const bool em3 = (i - 3 >= 0) && idx >= 3 && xs[idx - 3] == xs[idx - 2];
-                    const bool em2 = (i - 2 >= 0) && xs[idx - 2] == xs[idx - 1];
-                    const bool em1 = (i - 1 >= 0) && xs[idx - 1] == xs[idx];
-                    const bool ep1 = xs[idx] == xs[idx + 1];          // position p0 exists (p0 < nwin or flush tail)
-                    const bool ep2 = ((flush ? (i + 2 < (int64_t)g1) : true)) && xs[idx + 1] == xs[idx + 2];
-                    (void)em3;
-                    prev_same_in = ((em2 && em1) || (em1 && ep1) || (ep1 && ep2)) ? 1u : 0u;
-                }
-            }
-        }
-        uint32_t prev_same = prev_same_in;
+            const uint4 a = *(const uint4 *)(xs + p0);
+            const uint2 b = *(const uint2 *)(xs + p0 + 8);
+            const uint32_t c2 = *(const uint32_t *)(xs + p0 + 12);
+            const uint32_t d[7] = { a.x, a.y, a.z, a.w, b.x, b.y, c2 };
 #pragma unroll
-        for (int q = 0; q < TK_SPT; q++) {
-            const uint32_t p = tid * TK_SPT + q;
-            if (p < nwin) {
-                const int64_t i = (int64_t)g0 - 3 + p;
-                if (i >= 0) {
-                    const uint32_t idx = p + 3;
-                    const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
-                    const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
-                    const bool em2 = (i - 2 >= 0) && xs[idx - 2] == xs[idx - 1];
-                    const bool em1 = (i - 1 >= 0) && xs[idx - 1] == xs[idx];
-                    const bool ep1 = ex1 && xs[idx] == xs[idx + 1];
-                    const bool ep2 = ex2 && xs[idx + 1] == xs[idx + 2];
-                    const bool same = (em2 && em1) || (em1 && ep1) || (ep1 && ep2);
-                    const bool rs = !em1;                               // first symbol of a run
-                    const bool ss = !same && (i == 0 || prev_same);     // first symbol of a diff stretch
-                    if (same) same_bits |= 1u << q;
-                    if (rs) { same_bits |= 1u << (8 + q); my_run = (uint32_t)i + 1; }
-                    if (ss) { same_bits |= 1u << (16 + q); my_str = (uint32_t)i + 1; }
-                    prev_same = same ? 1u : 0u;
-                }
+            for (int m = 0; m < 14; m++) v[m] = (m & 1) ? (d[m >> 1] >> 16) : (d[m >> 1] & 0xFFFFu);
+        }
+        uint32_t EM = 0;                                        // bit m: x[i0-3+m] == x[i0-2+m] and both exist
+#pragma unroll
+        for (int m = 0; m < 13; m++) EM |= (v[m] == v[m + 1]) ? (1u << m) : 0u;
+        {
+            // pair m = symbols (a, a+1), a = g0 + p0 + m - 6: a >= 0, and a + 1 < g1 once the stream has ended
+            const int32_t mlo = 6 - (int32_t)(g0 + p0);
+            if (mlo > 0) EM &= (mlo >= 13) ? 0u : (0xFFFFFFFFu << mlo);
+            if (flush) {
+                const int32_t mhi = (int32_t)(g1 + 5) - (int32_t)(g0 + p0);      // pairs m < mhi exist
+                EM &= (mhi <= 0) ? 0u : (mhi >= 13 ? 0x1FFFu : ((1u << mhi) - 1u));
             }
         }
+        // validity of the 8 positions: p < nwin and i >= 0
+        uint32_t V = 0;
+        {
+            const uint32_t hi = (p0 >= nwin) ? 0u : min(nwin - p0, (uint32_t)TK_SPT);
+            V = (1u << hi) - 1u;
+            const int32_t lo = 3 - (int32_t)(g0 + p0);                           // positions q < lo have i < 0
+            if (lo > 0) V &= (lo >= 8) ? 0u : (0xFFu << lo);
+        }
+        const uint32_t A = EM & (EM >> 1);
+        const uint32_t SS = A | (A >> 1) | (A >> 2);            // bit q+1: symbol q sits in a run of >= 3; bit 0: the symbol before
+        const uint32_t SAME = (SS >> 1) & V;
+        const uint32_t RS = ~(EM >> 2) & V;                     // first symbol of a maximal run
+        uint32_t PREV = SS & 0xFFu;                             // bit q: isSame of symbol q-1
+        if (p0 == 0) PREV = (PREV & ~1u) | last_same;           // the symbol before the window was classified last tile
+        {
+            const int32_t q0 = 3 - (int32_t)(g0 + p0);          // position of symbol 0, if it is one of these 8
+            if (q0 >= 0 && q0 < 8) PREV |= 1u << q0;            // i == 0 opens a stretch whatever came "before"
+        }
+        const uint32_t STS = ~SAME & PREV & V;                  // first symbol of a diff stretch
+        const uint32_t LAST = ~(EM >> 3);                       // run ends here (next symbol differs or does not exist)
+        const uint32_t ibase = g0 + p0 - 2;                     // (i + 1) of position 0
+        const uint32_t my_run = RS ? ibase + (31 - __clz(RS)) : 0u;
+        const uint32_t my_str = STS ? ibase + (31 - __clz(STS)) : 0u;
         // exclusive max-scan of the thread-latest starts (positions grow with the thread index)
         const uint32_t run_incl = tk_wave_incl_max(my_run, lane), str_incl = tk_wave_incl_max(my_str, lane);
         if (lane == 63) { s_run[wave] = run_incl; s_str[wave] = str_incl; }
         uint32_t run_in = __shfl_up(run_incl, 1), str_in = __shfl_up(str_incl, 1);
         if (lane == 0) { run_in = 0; str_in = 0; }
         __syncthreads();
-        uint32_t run_tot = run1, str_tot = str1;
-#pragma unroll
-        for (int wv = 0; wv < TK_WAVES; wv++) {
-            const uint32_t a = s_run[wv], b = s_str[wv];
-            if ((uint32_t)wv < wave) { run_in = max(run_in, a); str_in = max(str_in, b); }
-            run_tot = max(run_tot, a); str_tot = max(str_tot, b);
+        uint32_t run_tot, str_tot;
+        {
+            uint32_t ra, sa;
+            tk_block16_max(s_run, wave, ra, run_tot);
+            tk_block16_max(s_str, wave, sa, str_tot);
+            run_in = max(max(run_in, ra), run1); str_in = max(max(str_in, sa), str1);
+            run_tot = max(run_tot, run1); str_tot = max(str_tot, str1);
         }
-        run_in = max(run_in, run1); str_in = max(str_in, str1);
         MIC_STAMP_AT(u, 1);
         // ---- C: tokens owned by each position ---------------------------------------------------
-        uint32_t tc[TK_SPT]; uint32_t kk[TK_SPT]; uint32_t tsum = 0;
-        {
-            uint32_t rcur = run_in, scur = str_in;
+        // k = 1-based index in the run, j = 1-based index in the stretch; rk = (k-3) % c, sj = (j-1) % c
+        uint32_t kq[TK_SPT], aq[TK_SPT];                        // per position: k or j, and rk or sj
+        uint32_t tcs = 0, tsum = 0;                             // 4-bit token counts, their sum
+        const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
+        if (V) {
+            // state of the symbol in front of position 0 (index i0 - 1 = ibase - 2)
+            uint32_t k = (run_in != 0 && ibase >= run_in + 1) ? ibase - run_in : 0u;       // (i0-1) + 2 - run_in
+            uint32_t j = (str_in != 0 && ibase >= str_in + 1) ? ibase - str_in : 0u;
+            uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
+            uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
-                const uint32_t p = tid * TK_SPT + q;
-                tc[q] = 0; kk[q] = 0;
-                if (p < nwin) {
-                    const int64_t i = (int64_t)g0 - 3 + p;
-                    if (i >= 0) {
-                        const uint32_t idx = p + 3;
-                        if (same_bits & (1u << (8 + q))) rcur = (uint32_t)i + 1;
-                        if (same_bits & (1u << (16 + q))) scur = (uint32_t)i + 1;
-                        const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
-                        const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
-                        if (same_bits & (1u << q)) {
-                            const uint32_t k = (uint32_t)i + 1 - rcur + 1;          // 1-based index in the run
-                            const bool last = !ex1 || xs[idx] != xs[idx + 1];
-                            uint32_t t = 0;
-                            if (k > 3 && (k - 3) % c == 0) t += 2;
-                            if (last) t += 2;
-                            tc[q] = t; kk[q] = k;
-                        } else {
-                            const uint32_t j = (uint32_t)i + 1 - scur + 1;          // 1-based index in the stretch
-                            const bool starts = (j == 1) || ((j - 1) % c == 0 && ex2);
-                            tc[q] = starts ? 2u : 1u; kk[q] = j;
-                        }
-                        tsum += tc[q];
+                const uint32_t bit = 1u << q;
+                kq[q] = 0; aq[q] = 0;
+                if (V & bit) {
+                    if (RS & bit) k = 1; else k++;
+                    if (k == 3) rk = 0; else if (k > 3) { rk++; if (rk == c) rk = 0; }
+                    if (STS & bit) { j = 1; sj = 0; } else { j++; sj++; if (sj == c) sj = 0; }
+                    uint32_t t;
+                    if (SAME & bit) {
+                        t = ((k > 3 && rk == 0) ? 2u : 0u) + ((LAST & bit) ? 2u : 0u);
+                        kq[q] = k; aq[q] = rk;
+                    } else {
+                        const bool ex2 = !flush || (g0 + p0 + q) < ex2_lim;
+                        t = ((j == 1) || (sj == 0 && ex2)) ? 2u : 1u;
+                        kq[q] = j; aq[q] = sj;
                     }
+                    tcs |= t << (4 * q); tsum += t;
                 }
             }
         }
         const uint32_t tincl = tk_wave_incl_add(tsum, lane);
         if (lane == 63) s_tc[wave] = tincl;
         __syncthreads();
-        uint32_t toff = 0, ttot = 0;
-#pragma unroll
-        for (int wv = 0; wv < TK_WAVES; wv++) { const uint32_t v = s_tc[wv]; if ((uint32_t)wv < wave) toff += v; ttot += v; }
+        uint32_t toff, ttot;
+        tk_block16_add(s_tc, wave, toff, ttot);
         MIC_STAMP_AT(u, 2);
         // ---- D: write ----------------------------------------------------------------------------
-        {
+        if (V) {
             uint32_t pos = outp + toff + tincl - tsum;
             bool ovf = false;
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
-                const uint32_t p = tid * TK_SPT + q;
-                if (tc[q] == 0 && !(p < nwin)) continue;
-                if (!(p < nwin)) continue;
-                const int64_t i = (int64_t)g0 - 3 + p;
-                if (i < 0) continue;
-                const uint32_t idx = p + 3;
-                const uint32_t xv = xs[idx];
-                const bool ex1 = flush ? (i + 1 < (int64_t)g1) : true;
-                const bool ex2 = flush ? (i + 2 < (int64_t)g1) : true;
-                const bool ex3 = flush ? (i + 3 < (int64_t)g1) : true;
-                if (same_bits & (1u << q)) {
-                    const uint32_t k = kk[q];
-                    if (k > 3 && (k - 3) % c == 0) {
+                const uint32_t bit = 1u << q;
+                if (!(V & bit)) continue;
+                const uint32_t xv = v[q + 3];
+                const uint32_t i3 = g0 + p0 + q;                                  // i + 3
+                if (SAME & bit) {
+                    const uint32_t k = kq[q], rk = aq[q];
+                    if (k > 3 && rk == 0) {
                         if (pos + 1 < cap) { tok[pos] = (uint16_t)c; tok[pos + 1] = (uint16_t)xv; count_tok(c); count_tok(xv); } else ovf = true;
                         pos += 2;
                     }
-                    const bool last = !ex1 || xv != xs[idx + 1];
-                    if (last) {
-                        const uint32_t rem = (k - 3) % c + 3;
+                    if (LAST & bit) {
+                        const uint32_t rem = rk + 3;                              // (k - 3) % c + 3
                         if (pos + 1 < cap) { tok[pos] = (uint16_t)rem; tok[pos + 1] = (uint16_t)xv; count_tok(rem); count_tok(xv); } else ovf = true;
                         pos += 2;
                     }
                 } else {
-                    const uint32_t j = kk[q];
-                    const uint32_t jm = (j - 1) % c;
+                    const uint32_t j = kq[q], jm = aq[q];
+                    const bool ex1 = !flush || i3 < g1 + 2, ex2 = !flush || i3 < g1 + 1, ex3 = !flush || i3 < g1;
                     const bool starts = (j == 1) || (jm == 0 && ex2);
                     const uint32_t lit = pos + (starts ? 1u : 0u);
                     if (lit < cap) { tok[lit] = (uint16_t)xv; count_tok(xv); } else ovf = true;
@@ -384,13 +433,14 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                     // does the chunk end here?  next symbol: end of stream / start of a same-run / opens a chunk
                     bool same_next;
                     if (!ex1) same_next = false;
-                    else if (xs[idx + 1] == xv) same_next = false;        // a run of 2 (this symbol is not in a same-run)
-                    else same_next = ex3 && xs[idx + 1] == xs[idx + 2] && xs[idx + 2] == xs[idx + 3];
-                    const bool next_starts = (j % c == 0) && ex3;
+                    else if (v[q + 4] == xv) same_next = false;                   // a run of 2 (this symbol is not in a same-run)
+                    else same_next = ex3 && v[q + 4] == v[q + 5] && v[q + 5] == v[q + 6];
+                    const bool next_starts = (jm + 1 == c) && ex3;                // j % c == 0
                     if (!ex1 || same_next || next_starts) {
                         uint32_t qlen = jm + 1;
                         // boundary suppressed for the last two symbols of the stream: they extend the previous chunk
-                        if (j - jm > 1 && !((i - (int64_t)jm + 2) < (int64_t)g1) && flush) qlen += c;
+                        // (chunk start symbol i - jm has no two symbols behind it: i3 - jm + 2 >= g1 + 3)
+                        if (flush && j > jm + 1 && !(i3 - jm + 2 < g1 + 3)) qlen += c;
                         if (lit >= qlen && lit - qlen < cap) { tok[lit - qlen] = (uint16_t)(mid + qlen); count_tok(mid + qlen); } else ovf = true;
                     }
                 }
@@ -401,17 +451,16 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         // ---- E: carry --------------------------------------------------------------------------------
         outp += ttot;
         run1 = run_tot; str1 = str_tot;
-        // isSame of the last processed symbol
         {
-            __syncthreads();
-            if (nwin > 0) {
+            // isSame of the last processed symbol (if any was processed), 6 symbols of halo for the next tile
+            if (nwin > 0 && g0 + nwin - 1 >= 3) {
                 const uint32_t pl = nwin - 1;
-                if (tid == pl / TK_SPT) s_cnt[0] = (same_bits >> (pl % TK_SPT)) & 1;
+                if (tid == pl / TK_SPT) s_last = (SAME >> (pl % TK_SPT)) & 1u;
             }
             uint16_t keep = 0;
             if (tid < 6) keep = xs[n + tid];
             __syncthreads();
-            if (nwin > 0 && ((int64_t)g0 - 3 + (int64_t)nwin - 1) >= 0) last_same = s_cnt[0];
+            last_same = s_last;
             if (tid < 6) xs[tid] = keep;
             __syncthreads();
         }
@@ -420,7 +469,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     }
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
-    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&ghist[hlo + i], v); }
+    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t vv = s_hist[i]; if (vv) atomicAdd(&ghist[hlo + i], vv); }
     if (tid == 0) {
         if (s_ovf || outp > cap) u.status = MICD_ERR_CAPACITY;
         else u.ntok = outp;
