@@ -141,16 +141,19 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 #define TK_PPT 4
 #define TK_SPT 8
 #define TK_WIN (TK_THREADS * TK_SPT)
-#define TK_HWIN 16384
+#define TK_HWIN 8192               // histogram window in LDS (with two symbol windows: two groups per CU)
 
-__device__ __forceinline__ uint32_t tk_wave_incl_add(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v += o; }
+// Wave-wide inclusive scans on the DPP network (row_shr 1/2/4/8, then row_bcast 15 and 31); lanes
+// without a source read the identity 0, so the same shape serves add and max.
+#define TK_DPP(x, ctrl, rmask) __builtin_amdgcn_update_dpp(0u, (x), (ctrl), (rmask), 0xF, false)
+__device__ __forceinline__ uint32_t tk_wave_incl_add(uint32_t v, uint32_t) {
+    v += TK_DPP(v, 0x111, 0xF); v += TK_DPP(v, 0x112, 0xF); v += TK_DPP(v, 0x114, 0xF); v += TK_DPP(v, 0x118, 0xF);
+    v += TK_DPP(v, 0x142, 0xA); v += TK_DPP(v, 0x143, 0xC);
     return v;
 }
-__device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v = max(v, o); }
+__device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t) {
+    v = max(v, TK_DPP(v, 0x111, 0xF)); v = max(v, TK_DPP(v, 0x112, 0xF)); v = max(v, TK_DPP(v, 0x114, 0xF)); v = max(v, TK_DPP(v, 0x118, 0xF));
+    v = max(v, TK_DPP(v, 0x142, 0xA)); v = max(v, TK_DPP(v, 0x143, 0xC));
     return v;
 }
 // 16 per-wave partials in LDS -> this wave's exclusive prefix and the group total (add / max)
@@ -180,16 +183,16 @@ typedef tk_v2 TkD __attribute__((aligned(2)));                 // 4 pixels, 2-by
 template <int SRC>
 __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    __shared__ __attribute__((aligned(16))) uint16_t xs[TK_WIN + 16];   // [0..5] = 6 symbols before the tile, [6..] = new symbols
+    __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per tile parity: [0..5] = 6 symbols before the tile, [6..] = new symbols
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
-    __shared__ uint32_t s_ovf, s_last;
+    __shared__ uint32_t s_ovf, s_last[2];
     // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
     if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
-    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last = 0; }
+    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last[0] = s_last[1] = 0; }
     const int depth = mic_len16(u.max_value);
     if (!SRC && (u.w <= 0 || u.h <= 0)) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
     if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
@@ -213,11 +216,10 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     uint32_t g0 = SRC ? 0u : 1u;     // symbols generated so far; frames: symbol 0 = maxValue is pre-seeded in the halo
     uint32_t outp = SRC ? 3u : 1u;   // tokens written so far; tok[0] = delimiter / max (rlecompressu16.go:21) [+ length words]
     uint32_t run1 = 0, str1 = 0;     // index+1 of the first symbol of the current run / diff stretch (0 = none)
-    uint32_t last_same = 0;
     const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
     uint32_t *ghist = u.hist;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
-    for (uint32_t i = tid; i < TK_WIN + 16; i += TK_THREADS) xs[i] = 0;
+    for (uint32_t i = tid; i < 2 * (TK_WIN + 16); i += TK_THREADS) (&xs2[0][0])[i] = 0;
     __syncthreads();
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
@@ -231,33 +233,48 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             } else s_ovf = 1;
         } else {
             if (cap > 0) { tok[0] = (uint16_t)delim; count_tok(delim); }
-            xs[5] = u.max_value;
+            xs2[0][5] = u.max_value;
         }
     }
     __syncthreads();
+    // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile)
+    struct TkFetch { tk_v2 cv, tv; uint32_t lft, x, y; bool row4; };
+    auto fetch = [&](uint32_t tile) -> TkFetch {
+        TkFetch f; f.cv = tk_v2{0u, 0u}; f.tv = tk_v2{0u, 0u}; f.lft = 0; f.x = 0; f.y = 0; f.row4 = false;
+        const uint32_t gb = tile * TP + tid * TK_PPT;
+        if (tile >= ntiles || gb >= npx) return f;
+        if (SRC) {
+            if (gb + TK_PPT <= npx) { f.cv = *(const TkD *)(in + gb); f.row4 = true; }
+            return f;
+        }
+        f.y = gb / W; f.x = gb - f.y * W;
+        f.row4 = f.x + TK_PPT <= W;                             // the 4 pixels share a row
+        if (f.row4) {
+            f.cv = *(const TkD *)(in + gb);
+            if (f.y > 0) f.tv = *(const TkD *)(in + gb - W);
+            if (f.x > 0) f.lft = in[gb - 1];
+        }
+        return f;
+    };
+    TkFetch nxt = fetch(0);
     MIC_STAMP_BEGIN();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
+        uint16_t *xs = xs2[tile & 1], *xs_next = xs2[(tile & 1) ^ 1];
         // ---- A: delta symbols of this tile's pixels (deltarlecompressu16.go:31-61) ----------
         uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0; int esc = 0;
         const uint32_t gbase = tile * TP + tid * TK_PPT;
+        const TkFetch f = nxt;
+        nxt = fetch(tile + 1);
         if (!flush && gbase < npx) {
+            const uint32_t cur[TK_PPT] = { f.cv.x & 0xFFFFu, f.cv.x >> 16, f.cv.y & 0xFFFFu, f.cv.y >> 16 };
             if (SRC) {
 #pragma unroll
-                for (int k = 0; k < TK_PPT; k++) if (gbase + k < npx) ls[cnt++] = in[gbase + k];
+                for (int k = 0; k < TK_PPT; k++) if (gbase + k < npx) ls[cnt++] = f.row4 ? cur[k] : (uint32_t)in[gbase + k];
             } else {
-                const uint32_t y = gbase / W, x = gbase - y * W;
-                uint32_t cur[TK_PPT], top[TK_PPT], lft = 0;
-                const bool row4 = x + TK_PPT <= W && gbase + TK_PPT <= npx;     // the 4 pixels share a row
-                if (row4) {
-                    const tk_v2 cv = *(const TkD *)(in + gbase);
-                    cur[0] = cv.x & 0xFFFFu; cur[1] = cv.x >> 16; cur[2] = cv.y & 0xFFFFu; cur[3] = cv.y >> 16;
-                    if (y > 0) {
-                        const tk_v2 tv = *(const TkD *)(in + gbase - W);
-                        top[0] = tv.x & 0xFFFFu; top[1] = tv.x >> 16; top[2] = tv.y & 0xFFFFu; top[3] = tv.y >> 16;
-                    } else top[0] = top[1] = top[2] = top[3] = 0;
-                    if (x > 0) lft = in[gbase - 1];
-                }
+                const uint32_t top[TK_PPT] = { f.tv.x & 0xFFFFu, f.tv.x >> 16, f.tv.y & 0xFFFFu, f.tv.y >> 16 };
+                const uint32_t x = f.x, y = f.y;
+                const bool row4 = f.row4;
 #pragma unroll
                 for (int k = 0; k < TK_PPT; k++) {
                     const uint32_t g = gbase + k;
@@ -265,7 +282,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                     uint32_t val; int32_t prev;
                     if (row4) {
                         val = cur[k];
-                        const uint32_t l = k ? cur[k - 1] : lft;
+                        const uint32_t l = k ? cur[k - 1] : f.lft;
                         if (x + k > 0 && y > 0) prev = (int32_t)((l + top[k]) >> 1);
                         else if (x + k > 0) prev = (int32_t)l;
                         else prev = (int32_t)top[k];                        // 0 on row 0
@@ -299,6 +316,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
 #pragma unroll
         for (int k = 0; k < 2 * TK_PPT; k++) if ((uint32_t)k < cnt) xs[6 + off + k] = (uint16_t)ls[k];
         __syncthreads();
+        if (tid < 6) xs_next[tid] = xs[n + tid];                // halo of the next tile (its window is idle until then)
         const uint32_t g1 = g0 + n;
         MIC_STAMP_AT(u, 0);
         // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3];  i3 = i + 3 = g0 + p keeps the arithmetic unsigned
@@ -339,7 +357,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         const uint32_t SAME = (SS >> 1) & V;
         const uint32_t RS = ~(EM >> 2) & V;                     // first symbol of a maximal run
         uint32_t PREV = SS & 0xFFu;                             // bit q: isSame of symbol q-1
-        if (p0 == 0) PREV = (PREV & ~1u) | last_same;           // the symbol before the window was classified last tile
+        if (p0 == 0) PREV = (PREV & ~1u) | s_last[(tile & 1) ^ 1];   // the symbol before the window was classified last tile
         {
             const int32_t q0 = 3 - (int32_t)(g0 + p0);          // position of symbol 0, if it is one of these 8
             if (q0 >= 0 && q0 < 8) PREV |= 1u << q0;            // i == 0 opens a stretch whatever came "before"
@@ -367,7 +385,8 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         // ---- C: tokens owned by each position ---------------------------------------------------
         // k = 1-based index in the run, j = 1-based index in the stretch; rk = (k-3) % c, sj = (j-1) % c
         uint32_t kq[TK_SPT], aq[TK_SPT];                        // per position: k or j, and rk or sj
-        uint32_t tcs = 0, tsum = 0;                             // 4-bit token counts, their sum
+        uint32_t tsum = 0;
+        bool fast = false;                                      // 8 plain literals inside one chunk: the usual case in noisy data
         const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
         if (V) {
             // state of the symbol in front of position 0 (index i0 - 1 = ibase - 2)
@@ -375,6 +394,11 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             uint32_t j = (str_in != 0 && ibase >= str_in + 1) ? ibase - str_in : 0u;
             uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
             uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
+            // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start, and the
+            // chunk neither starts nor ends here: sj + 1 .. sj + 8 stay inside [1, c - 2]
+            fast = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && sj + 10 <= c;
+            if (fast) tsum = TK_SPT;
+            else
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
                 const uint32_t bit = 1u << q;
@@ -392,7 +416,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                         t = ((j == 1) || (sj == 0 && ex2)) ? 2u : 1u;
                         kq[q] = j; aq[q] = sj;
                     }
-                    tcs |= t << (4 * q); tsum += t;
+                    tsum += t;
                 }
             }
         }
@@ -403,7 +427,26 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         tk_block16_add(s_tc, wave, toff, ttot);
         MIC_STAMP_AT(u, 2);
         // ---- D: write ----------------------------------------------------------------------------
-        if (V) {
+        if (fast) {
+            const uint32_t pos = outp + toff + tincl - tsum;
+            if (pos + TK_SPT <= cap) {
+                typedef uint32_t tk_v4 __attribute__((ext_vector_type(4)));
+                typedef tk_v4 TkQ __attribute__((aligned(2)));
+                tk_v4 o;
+                o.x = v[3] | (v[4] << 16); o.y = v[5] | (v[6] << 16); o.z = v[7] | (v[8] << 16); o.w = v[9] | (v[10] << 16);
+                *(TkQ *)(tok + pos) = o;
+                uint32_t dmax = 0;                               // one window test for the 8 values
+#pragma unroll
+                for (int q = 0; q < TK_SPT; q++) dmax = max(dmax, v[q + 3] - hlo);
+                if (dmax < TK_HWIN) {
+#pragma unroll
+                    for (int q = 0; q < TK_SPT; q++) atomicAdd(&s_hist[v[q + 3] - hlo], 1u);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TK_SPT; q++) count_tok(v[q + 3]);
+                }
+            } else s_ovf = 1;
+        } else if (V) {
             uint32_t pos = outp + toff + tincl - tsum;
             bool ovf = false;
 #pragma unroll
@@ -449,20 +492,15 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         }
         MIC_STAMP_AT(u, 3);
         // ---- E: carry --------------------------------------------------------------------------------
+        // (the barriers of the next tile order these LDS words; both are double-buffered by tile parity)
         outp += ttot;
         run1 = run_tot; str1 = str_tot;
         {
-            // isSame of the last processed symbol (if any was processed), 6 symbols of halo for the next tile
-            if (nwin > 0 && g0 + nwin - 1 >= 3) {
-                const uint32_t pl = nwin - 1;
-                if (tid == pl / TK_SPT) s_last = (SAME >> (pl % TK_SPT)) & 1u;
-            }
-            uint16_t keep = 0;
-            if (tid < 6) keep = xs[n + tid];
-            __syncthreads();
-            last_same = s_last;
-            if (tid < 6) xs[tid] = keep;
-            __syncthreads();
+            // isSame of the last processed symbol, or the previous value when none was processed
+            const bool processed = nwin > 0 && g0 + nwin - 1 >= 3;
+            const uint32_t pl = processed ? nwin - 1 : 0u;
+            if (processed) { if (tid == pl / TK_SPT) s_last[tile & 1] = (SAME >> (pl % TK_SPT)) & 1u; }
+            else if (tid == 0) s_last[tile & 1] = s_last[(tile & 1) ^ 1];
         }
         g0 = g1;
         MIC_STAMP_AT(u, 4);
