@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         MIC_STAMP_AT(u, 1);
         // ---- C: tokens owned by each position ---------------------------------------------------
         // k = 1-based index in the run, j = 1-based index in the stretch; rk = (k-3) % c, sj = (j-1) % c
-        uint32_t kq[TK_SPT], aq[TK_SPT];                        // per position: k or j, and rk or sj
+        uint32_t k_in = 0, j_in = 0, rk_in = 0, sj_in = 0;     // state in front of position 0 (D replays the recurrence)
         uint32_t tsum = 0;
         bool fast = false;                                      // 8 plain literals inside one chunk: the usual case in noisy data
         const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
@@ -394,6 +394,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
             uint32_t j = (str_in != 0 && ibase >= str_in + 1) ? ibase - str_in : 0u;
             uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
             uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
+            k_in = k; j_in = j; rk_in = rk; sj_in = sj;
             // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start, and the
             // chunk neither starts nor ends here: sj + 1 .. sj + 8 stay inside [1, c - 2]
             fast = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && sj + 10 <= c;
@@ -402,7 +403,6 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
                 const uint32_t bit = 1u << q;
-                kq[q] = 0; aq[q] = 0;
                 if (V & bit) {
                     if (RS & bit) k = 1; else k++;
                     if (k == 3) rk = 0; else if (k > 3) { rk++; if (rk == c) rk = 0; }
@@ -410,11 +410,9 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                     uint32_t t;
                     if (SAME & bit) {
                         t = ((k > 3 && rk == 0) ? 2u : 0u) + ((LAST & bit) ? 2u : 0u);
-                        kq[q] = k; aq[q] = rk;
                     } else {
                         const bool ex2 = !flush || (g0 + p0 + q) < ex2_lim;
                         t = ((j == 1) || (sj == 0 && ex2)) ? 2u : 1u;
-                        kq[q] = j; aq[q] = sj;
                     }
                     tsum += t;
                 }
@@ -449,14 +447,17 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
         } else if (V) {
             uint32_t pos = outp + toff + tincl - tsum;
             bool ovf = false;
+            uint32_t k = k_in, j = j_in, rk = rk_in, sj = sj_in;
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
                 const uint32_t bit = 1u << q;
                 if (!(V & bit)) continue;
+                if (RS & bit) k = 1; else k++;
+                if (k == 3) rk = 0; else if (k > 3) { rk++; if (rk == c) rk = 0; }
+                if (STS & bit) { j = 1; sj = 0; } else { j++; sj++; if (sj == c) sj = 0; }
                 const uint32_t xv = v[q + 3];
                 const uint32_t i3 = g0 + p0 + q;                                  // i + 3
                 if (SAME & bit) {
-                    const uint32_t k = kq[q], rk = aq[q];
                     if (k > 3 && rk == 0) {
                         if (pos + 1 < cap) { tok[pos] = (uint16_t)c; tok[pos + 1] = (uint16_t)xv; count_tok(c); count_tok(xv); } else ovf = true;
                         pos += 2;
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
                         pos += 2;
                     }
                 } else {
-                    const uint32_t j = kq[q], jm = aq[q];
+                    const uint32_t jm = sj;
                     const bool ex1 = !flush || i3 < g1 + 2, ex2 = !flush || i3 < g1 + 1, ex3 = !flush || i3 < g1;
                     const bool starts = (j == 1) || (jm == 0 && ex2);
                     const uint32_t lit = pos + (starts ? 1u : 0u);
@@ -772,25 +773,35 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         return (state + tt_nb[sy]) >> 16;
     };
     MIC_STAMP_BEGIN();
-    uint32_t st[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
-    for (uint32_t b = b_hi; b > b_lo; b--) {
-        const uint32_t base = (b - 1) * TE_BLK;
+    // Per 32-token block the walk leaves a record in HBM: the N states after the block (u16, minus 2^tl)
+    // and the bits the block emits.  Fix-up compares and replaces records; packing needs none of them
+    // (it walks again from the true start states), so tokens are read twice and states never stored.
+    constexpr uint32_t RW = N + 1;
+    auto walk_block = [&](uint32_t base, uint32_t (&stw)[N]) -> uint32_t {
         const TeBlk tk = te_load(src + base);
-        TeBlk rec;                                   // every half-word is written below; start defined (no poison)
-        rec.v[0] = rec.v[1] = rec.v[2] = rec.v[3] = make_uint4(0, 0, 0, 0);
+        uint32_t bits = 0;
 #pragma unroll
         for (int j = TE_BLK - 1; j >= 0; j--) {
             if (base + (uint32_t)j < n) {
-                const uint32_t sy = te_get(tk, j);
                 const int k = j & (N - 1);
-                te_set(rec, j, st[k] - size);
                 uint32_t nb;
-                st[k] = step(st[k], sy, nb);
-            } else te_set(rec, j, 0);
+                stw[k] = step(stw[k], te_get(tk, j), nb);
+                bits += nb;
+            }
         }
-        te_store(stv + base, rec);
+        return bits;
+    };
+    uint32_t st[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
+    uint32_t mybits = 0;
+    for (uint32_t b = b_hi; b > b_lo; b--) {
+        const uint32_t bits = walk_block((b - 1) * TE_BLK, st);
+        mybits += bits;
+        uint16_t *r = stv + (size_t)(b - 1) * RW;
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = (uint16_t)(st[k] - size);
+        r[N] = (uint16_t)bits;
     }
 #pragma unroll
     for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
@@ -802,44 +813,31 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     for (uint32_t round = 0; round < TE_THREADS; round++) {
         __syncthreads();
         int changed = 0;
-        uint32_t e_out[N], st2[N]; bool act[N]; bool any = false;
+        uint32_t e_out[N], st2[N]; bool any = false;
 #pragma unroll
         for (int k = 0; k < N; k++) {
             e_out[k] = (uint32_t)s_E[tid][k] + size;
             const uint32_t e_prev = (tid > 0) ? (uint32_t)s_E[tid - 1][k] + size : size;
-            act[k] = (tid > 0) && (e_prev != assumed[k]) ;
-            if (act[k]) { assumed[k] = e_prev; any = true; }
+            if (tid > 0 && e_prev != assumed[k]) { assumed[k] = e_prev; any = true; }
             st2[k] = e_prev;
         }
         if (any) {
-            if (b_hi == b_lo) {            // no tokens: hand the states on (never asks for another round)
+            bool merged = false;
+            for (uint32_t b = b_hi; b > b_lo && !merged; b--) {
+                const uint32_t bits = walk_block((b - 1) * TE_BLK, st2);
+                uint16_t *r = stv + (size_t)(b - 1) * RW;
+                merged = true;
 #pragma unroll
-                for (int k = 0; k < N; k++) if (act[k]) e_out[k] = st2[k];
-            } else {
-                for (uint32_t b = b_hi; b > b_lo && any; b--) {
-                    const uint32_t base = (b - 1) * TE_BLK;
-                    const TeBlk tk = te_load(src + base);
-                    TeBlk rec = te_load(stv + base);
-#pragma unroll
-                    for (int j = TE_BLK - 1; j >= 0; j--) {
-                        const int k = j & (N - 1);
-                        if (base + (uint32_t)j < n && act[k]) {
-                            if (te_get(rec, j) + size == st2[k]) act[k] = false;       // merged with the recorded walk
-                            else {
-                                const uint32_t sy = te_get(tk, j);
-                                te_set(rec, j, st2[k] - size);
-                                uint32_t nb;
-                                st2[k] = step(st2[k], sy, nb);
-                            }
-                        }
-                    }
-                    te_store(stv + base, rec);
-                    any = false;
-#pragma unroll
-                    for (int k = 0; k < N; k++) any = any || act[k];
+                for (int k = 0; k < N; k++) {
+                    if ((uint32_t)r[k] + size != st2[k]) merged = false;
+                    r[k] = (uint16_t)(st2[k] - size);
                 }
+                mybits += bits - (uint32_t)r[N];
+                r[N] = (uint16_t)bits;
+            }
+            if (!merged) {                                   // ran to the end of the range (or owns no tokens): hand the states on
 #pragma unroll
-                for (int k = 0; k < N; k++) if (act[k] && st2[k] != e_out[k]) { e_out[k] = st2[k]; changed = 1; }
+                for (int k = 0; k < N; k++) if (st2[k] != e_out[k]) { e_out[k] = st2[k]; changed = 1; }
             }
         }
         __syncthreads();                                   // every thread has read its predecessor's states
@@ -859,15 +857,6 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     __syncthreads();
     MIC_STAMP_AT(u, 9);
     // ---- 3. bit offsets ---------------------------------------------------------------------------
-    uint32_t mybits = 0;
-    for (uint32_t b = b_hi; b > b_lo; b--) {
-        const uint32_t base = (b - 1) * TE_BLK;
-        const TeBlk tk = te_load(src + base);
-        const TeBlk rec = te_load(stv + base);
-#pragma unroll
-        for (int j = TE_BLK - 1; j >= 0; j--)
-            if (base + (uint32_t)j < n) mybits += nbits(te_get(rec, j) + size, te_get(tk, j));
-    }
     const uint32_t incl = tk_wave_incl_add(mybits, lane);
     if (lane == 63) s_scan[wave] = incl;
     __syncthreads();
@@ -896,21 +885,28 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     uint32_t w = first_w;
     uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 31);
     uint32_t lead_val = 0; bool have_lead = false;
-    for (uint32_t b = b_hi; b > b_lo; b--) {
-        const uint32_t base = (b - 1) * TE_BLK;
-        const TeBlk tk = te_load(src + base);
-        const TeBlk rec = te_load(stv + base);
+    {
+        uint32_t stp[N];
+        const uint32_t lastown = (nblk + per - 1) / per;   // threads 0 .. lastown-1 own tokens; s_E[T-1] was overwritten for the trailer
 #pragma unroll
-        for (int j = TE_BLK - 1; j >= 0; j--) {
-            if (base + (uint32_t)j < n) {
-                const uint32_t stt = te_get(rec, j) + size;
-                const uint32_t nb = nbits(stt, te_get(tk, j));
-                acc |= (uint64_t)(stt & ((1u << nb) - 1u)) << filled;   // nb <= 16
-                filled += nb;
-                if (filled >= 32) {
-                    if (w > first_w || own_first) words[w] = (uint32_t)acc;
-                    else { lead_val = (uint32_t)acc; have_lead = true; }
-                    acc >>= 32; filled -= 32; w++;
+        for (int k = 0; k < N; k++) stp[k] = (tid > 0 && tid < lastown) ? (uint32_t)s_E[tid - 1][k] + size : size;
+        for (uint32_t b = b_hi; b > b_lo; b--) {
+            const uint32_t base = (b - 1) * TE_BLK;
+            const TeBlk tk = te_load(src + base);
+#pragma unroll
+            for (int j = TE_BLK - 1; j >= 0; j--) {
+                if (base + (uint32_t)j < n) {
+                    const int k = j & (N - 1);
+                    const uint32_t stt = stp[k];
+                    uint32_t nb;
+                    stp[k] = step(stt, te_get(tk, j), nb);
+                    acc |= (uint64_t)(stt & ((1u << nb) - 1u)) << filled;   // nb <= 16
+                    filled += nb;
+                    if (filled >= 32) {
+                        if (w > first_w || own_first) words[w] = (uint32_t)acc;
+                        else { lead_val = (uint32_t)acc; have_lead = true; }
+                        acc >>= 32; filled -= 32; w++;
+                    }
                 }
             }
         }
