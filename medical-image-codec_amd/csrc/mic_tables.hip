@@ -39,6 +39,110 @@ __device__ __forceinline__ uint32_t tb_wave_max(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------
+// writeCount (fsecompressu16.go:191-289) on the whole group, for tableLog <= 14 (a field is at most
+// 15 bits there, so the reference's 32-bit accumulator never drops any; above that the serial
+// writer reproduces its wrap-around).  The header is a concatenation of bit fields, LSB first:
+//   [4: tableLog-5] then, per written symbol s,  [run code][count field]
+// * written symbols: every non-zero count and the first zero of a zero-run; the other zeros of a
+//   run (R of them) become the run code in front of the next written symbol: 16 one-bits per 24,
+//   then 2 one-bits per 3, then R % 24 % 3 in 2 bits;
+// * count field: remaining = 2^tl + 1 - sum of |count| before s (a prefix sum), threshold = the
+//   largest power of two <= remaining (at most 2^tl), nbBits = log2(threshold) + 1,
+//   max = 2*threshold - 1 - remaining, v = count + 1 (+ max when v >= threshold), nbBits - 1 bits when v < max.
+// Bit offsets are a second prefix sum; fields are OR-ed into an LDS bit buffer and copied out.
+// rem16 / s016: symbol_len u16 each, bitbuf: zero-initialised here, ((symbol_len * tl) >> 3) + 8 bytes.
+__device__ int tb_write_ncount_par(const int16_t *norm, uint32_t symbol_len, uint32_t tl, uint16_t *rem16, uint16_t *s016,
+                                   uint32_t *bitbuf, uint32_t *s_tmp, uint8_t *out, uint32_t cap, uint32_t *hdr_len) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t size = 1u << tl;
+    const uint32_t max_header = ((symbol_len * tl) >> 3) + 3;
+    if (cap < max_header + 2) return MICD_ERR_CAPACITY;
+    const uint32_t nwords = (max_header + 8 + 3) / 4;
+    for (uint32_t i = tid; i < nwords; i += TP_THREADS) bitbuf[i] = 0;
+    // pass A: remaining in front of every symbol, first zero of the run a symbol closes
+    uint32_t carry_sum = 0, carry_fz = 0;
+    for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
+        const uint32_t s2 = base + tid;
+        const int32_t v = (s2 < symbol_len) ? (int32_t)norm[s2] : 0;
+        const int32_t vp = (s2 > 0 && s2 < symbol_len) ? (int32_t)norm[s2 - 1] : 1;
+        uint32_t tot;
+        const uint32_t ex = tp_block_excl((uint32_t)(v < 0 ? -v : v), s_tmp, &tot);
+        // exclusive max-scan of (index + 1) of first zeros
+        const uint32_t fz = (s2 < symbol_len && v == 0 && vp != 0) ? s2 + 1 : 0u;
+        uint32_t mi = fz;
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(mi, d); if (lane >= (uint32_t)d) mi = max(mi, o); }
+        uint32_t me = __shfl_up(mi, 1); if (lane == 0) me = 0;
+        __syncthreads();
+        if (lane == 63) s_tmp[32 + wave] = mi;
+        __syncthreads();
+        uint32_t mtot = carry_fz;
+        for (uint32_t w = 0; w < TP_WAVES; w++) { const uint32_t x = s_tmp[32 + w]; if (w < wave) me = max(me, x); mtot = max(mtot, x); }
+        me = max(me, carry_fz);
+        if (s2 < symbol_len) { rem16[s2] = (uint16_t)(size + 1 - (carry_sum + ex)); s016[s2] = (uint16_t)me; }
+        carry_sum += tot; carry_fz = mtot;
+    }
+    if (carry_sum != size) return MICD_ERR_INTERNAL;          // (the serial writer ends with remaining != 1)
+    __syncthreads();
+    // field of symbol s: ones (run code body), then `lo` = [2-bit run remainder][count field] in lo_len bits
+    auto field = [&](uint32_t s2, uint32_t &ones, uint32_t &lo, uint32_t &lo_len) {
+        ones = 0; lo = 0; lo_len = 0;
+        const int32_t v = (int32_t)norm[s2];
+        const int32_t vp = s2 > 0 ? (int32_t)norm[s2 - 1] : 1;
+        if (v == 0 && vp == 0) return;                                    // inside a zero run: part of the run code
+        if (vp == 0) {                                                    // closes a run of R + 1 zeros
+            const uint32_t R = s2 - (uint32_t)s016[s2];
+            const uint32_t r24 = R % 24;
+            ones = 16 * (R / 24) + 2 * (r24 / 3);
+            lo = r24 % 3; lo_len = 2;
+        }
+        const int32_t remaining = (int32_t)rem16[s2];
+        const uint32_t hb = min(tl, (uint32_t)(31 - __clz((uint32_t)remaining)));
+        const int32_t threshold = 1 << hb;
+        const uint32_t nbb = hb + 1;
+        const int32_t mx = (2 * threshold - 1) - remaining;
+        int32_t cnt = v + 1;
+        if (cnt >= threshold) cnt += mx;
+        const uint32_t flen = nbb - ((cnt < mx) ? 1u : 0u);
+        lo |= (uint32_t)cnt << lo_len; lo_len += flen;
+    };
+    // pass B: offsets and packing
+    uint32_t carry_bits = 4;
+    if (tid == 0) atomicOr(&bitbuf[0], tl - MIC_MIN_TABLELOG);
+    for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
+        const uint32_t s2 = base + tid;
+        uint32_t ones = 0, lo = 0, lo_len = 0;
+        if (s2 < symbol_len) field(s2, ones, lo, lo_len);
+        uint32_t tot;
+        const uint32_t ex = tp_block_excl(ones + lo_len, s_tmp, &tot);
+        uint32_t pos = carry_bits + ex;
+        if (ones) {                                                       // bits [pos, pos + ones) set
+            uint32_t left = ones;
+            while (left) {
+                const uint32_t sh = pos & 31, take = min(left, 32u - sh);
+                const uint32_t m = (take == 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << sh;
+                atomicOr(&bitbuf[pos >> 5], m);
+                pos += take; left -= take;
+            }
+        }
+        if (lo_len) {
+            const uint32_t sh = pos & 31;
+            atomicOr(&bitbuf[pos >> 5], lo << sh);
+            if (sh + lo_len > 32) atomicOr(&bitbuf[(pos >> 5) + 1], lo >> (32 - sh));
+        }
+        carry_bits += tot;
+    }
+    __syncthreads();
+    const uint32_t nbytes = (carry_bits + 7) >> 3;
+    if (nbytes > max_header) return MICD_ERR_INTERNAL;
+    const uint8_t *bb = (const uint8_t *)bitbuf;
+    for (uint32_t i = tid; i < nbytes + 8; i += TP_THREADS) out[i] = (i < nbytes) ? bb[i] : (uint8_t)0;   // + the 8 bytes k_enc_tans_wg ORs into
+    *hdr_len = nbytes;
+    return MICD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 template <typename NormT, typename IdxT>
 __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT *cum_all, uint16_t *visit_pos,
                                 uint32_t *bitmap, uint32_t *wprefix, uint32_t *big_list, uint32_t *s_tmp,
@@ -197,7 +301,13 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     __syncthreads();
     MIC_STAMP_AT(u, 5);
     // ---- NCount header (one lane; fsecompressu16.go:191-289) ----------------------------------------
-    if (tid == 0) {
+    if (sizeof(NormT) == 2 && tl <= 14 && u.blob_cap >= 6 + 16) {
+        // LDS scratch that tp_build only needs later: first_visit / cum_all hold the two u16 arrays, visit_pos the bit buffer
+        uint32_t hdr = 0;
+        const int rc = tb_write_ncount_par((const int16_t *)norm, symbol_len, tl, (uint16_t *)first_visit, (uint16_t *)cum_all,
+                                           (uint32_t *)visit_pos, s_tmp, u.blob + 6, u.blob_cap - 6 - 8, &hdr);
+        if (tid == 0) { if (rc == MICD_OK) u.hdr_len = hdr; s_misc[3] = (uint32_t)rc; }
+    } else if (tid == 0) {
         int rc = MICD_OK;
         uint32_t hdr = 0;
         if (u.blob_cap < 6 + 8) rc = MICD_ERR_CAPACITY;
@@ -208,6 +318,7 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
         }
         s_misc[3] = (uint32_t)rc;
     }
+    __threadfence_block();
     __syncthreads();
     if ((int)s_misc[3] != MICD_OK) { if (tid == 0) u.status = (int)s_misc[3]; return; }
     MIC_STAMP_AT(u, 6);
