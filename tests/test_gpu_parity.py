@@ -286,6 +286,36 @@ def test_fse_stage_edge_cases(mic, mico, gpu_ready, flavour):
             assert np.array_equal(mic.fse_decompress_u16_auto(got, n + 8), data)
 
 
+@pytest.mark.parametrize("flavour", [2, 8])
+def test_fse_stage_sparse_alphabets_ncount_run_codes(mic, mico, synth, gpu_ready, flavour):
+    """Zero-runs of 1, 2, 3, 23, 24, 25, 71, 72 and ~3000 symbols in the normalised counts: the NCount header's
+    0xFFFF / '11' / 2-bit run codes (fsecompressu16.go:207-236) at every boundary."""
+    r = synth.hash_u64(60000, 5)
+    for gaps in ([1, 2, 3, 4], [23, 24, 25, 26], [71, 72, 73, 3000], [48, 96, 24 * 5 + 3, 24 * 7 + 2]):
+        vals = np.cumsum([3] + [g + 1 for g in gaps]).astype(np.uint16)        # gaps[i] zeros between used symbols
+        vals = np.concatenate([[0, 1, 2], vals]).astype(np.uint16)
+        # skewed use so that counts differ (some symbols become -1)
+        idx = np.minimum((r % np.uint64(97)) % np.uint64(len(vals) * 3), np.uint64(len(vals) - 1)).astype(np.int64)
+        data = vals[idx]
+        rc, want = mico.fse_compress(data, flavour)
+        assert rc == 0, gaps
+        got = mic.fse_compress_u16(data, flavour)
+        assert got == want, gaps
+        assert np.array_equal(mic.fse_decompress_u16_auto(got, data.size + 8), data)
+
+
+@pytest.mark.parametrize("w,h", [(8200, 3), (9001, 70), (33000, 2), (40000, 3)])
+def test_wide_frames_row_buffer_classes(mic, mico, synth, gpu_ready, w, h):
+    """Frames wider than the ordinary row-buffer class of the predictor kernel, and wider than any (fallback path)."""
+    noise = (synth.hash_u64(w * h, w + h) % np.uint64(5)).astype(np.int64).reshape(h, w)
+    img = ((np.add.outer(np.arange(h) * 7, np.arange(w) // 8) + noise) % 4096).astype(np.uint16)
+    rc, want = mico.compress_single_frame(img, 4095, 2)
+    assert rc == 0
+    got = mic.compress_single_frame(img, w, h, 4095, 2)
+    assert got == want
+    assert np.array_equal(np.asarray(mic.decompress_single_frame(got, w, h)).reshape(-1), img.reshape(-1))
+
+
 def test_fse_stage_incompressible_noise(mic, synth, gpu_ready):
     noise = (synth.hash_u64(1 << 21, 9) & np.uint64(0xFFFF)).astype(np.uint16)
     for flavour in (2, 108):
