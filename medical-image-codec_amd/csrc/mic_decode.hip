@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
     const int32_t top_dw = (cur0 - 1) >> 5;                             // dword holding the top unread bit
     auto load_blk = [&](int32_t b) -> uint32_t {                        // 64 dwords of block b, zero outside the stream
         const int32_t idx = b * 64 + (int32_t)lane;
-        return (b >= 0 && idx <= top_dw) ? g[idx] : 0u;
+        return (b >= 0 && idx <= top_dw) ? __builtin_nontemporal_load(g + idx) : 0u;   // streamed once: keep L2 for the symbol tables
     };
     auto store_blk = [&](int32_t b, uint32_t v) {
         const uint32_t slot = ((uint32_t)b & 3u) * 64u + lane;
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
         store_blk(blk - 2, pf);
         if (have_pend) {
             const uint32_t pk = pend_lo | (pend_hi << 16);
-            ((gu32)out)[obase + lane] = pk;
+            __builtin_nontemporal_store(pk, (gu32)out + obase + lane);
             const uint32_t cb = obase * 2;
             walk(cb + 128, [&](uint32_t pos) -> uint32_t {
                 const uint32_t rel = pos - cb;

@@ -707,6 +707,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_THREADS 1024
 #define TE_WAVES 16
 #define TE_BLK 32                 // tokens per 64-byte block
+#define TE_RGRP 4                 // blocks per fix-up record
 #define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
 
 // One block of 32 tokens / 32 recorded states as four 16-byte vectors.
@@ -773,10 +774,31 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         return (state + tt_nb[sy]) >> 16;
     };
     MIC_STAMP_BEGIN();
-    // Per 32-token block the walk leaves a record in HBM: the N states after the block (u16, minus 2^tl)
-    // and the bits the block emits.  Fix-up compares and replaces records; packing needs none of them
-    // (it walks again from the true start states), so tokens are read twice and states never stored.
-    constexpr uint32_t RW = N + 1;
+    // Per group of TE_RGRP blocks (128 tokens) the walk leaves a record in HBM: the N states after the group
+    // (u16, minus 2^tl) and the bits the group emits, one aligned vector store.  Fix-up compares and replaces
+    // records; packing needs none of them (it walks again from the true start states), so tokens are read
+    // twice and states never stored.  Record slot = tid * gper + group index inside the thread's range.
+    constexpr uint32_t RWP = (N == 1) ? 2u : 2u * N;       // u16 per record: N states, the bit count, padding
+    const uint32_t gper = (per + TE_RGRP - 1) / TE_RGRP;
+    uint32_t *const rec32 = (uint32_t *)stv + (size_t)tid * gper * (RWP / 2);
+    auto rec_store = [&](uint32_t g, const uint32_t (&stw)[N], uint32_t bits) {
+        uint32_t w[RWP / 2];
+#pragma unroll
+        for (uint32_t i = 0; i < RWP / 2; i++) w[i] = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) w[k >> 1] |= ((stw[k] - size) & 0xFFFFu) << (16 * (k & 1));
+        w[N >> 1] |= (bits & 0xFFFFu) << (16 * (N & 1));
+#pragma unroll
+        for (uint32_t i = 0; i < RWP / 2; i++) rec32[(size_t)g * (RWP / 2) + i] = w[i];
+    };
+    auto rec_load = [&](uint32_t g, uint32_t (&stw)[N], uint32_t &bits) {
+        uint32_t w[RWP / 2];
+#pragma unroll
+        for (uint32_t i = 0; i < RWP / 2; i++) w[i] = rec32[(size_t)g * (RWP / 2) + i];
+#pragma unroll
+        for (int k = 0; k < N; k++) stw[k] = ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) + size;
+        bits = (w[N >> 1] >> (16 * (N & 1))) & 0xFFFFu;
+    };
     auto walk_block = [&](uint32_t base, uint32_t (&stw)[N]) -> uint32_t {
         const TeBlk tk = te_load(src + base);
         uint32_t bits = 0;
@@ -795,13 +817,11 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
 #pragma unroll
     for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
     uint32_t mybits = 0;
-    for (uint32_t b = b_hi; b > b_lo; b--) {
-        const uint32_t bits = walk_block((b - 1) * TE_BLK, st);
+    for (uint32_t g = 0, b = b_hi; b > b_lo; g++) {
+        uint32_t bits = 0;
+        for (uint32_t r = 0; r < TE_RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * TE_BLK, st);
         mybits += bits;
-        uint16_t *r = stv + (size_t)(b - 1) * RW;
-#pragma unroll
-        for (int k = 0; k < N; k++) r[k] = (uint16_t)(st[k] - size);
-        r[N] = (uint16_t)bits;
+        rec_store(g, st, bits);
     }
 #pragma unroll
     for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
@@ -823,17 +843,16 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         }
         if (any) {
             bool merged = false;
-            for (uint32_t b = b_hi; b > b_lo && !merged; b--) {
-                const uint32_t bits = walk_block((b - 1) * TE_BLK, st2);
-                uint16_t *r = stv + (size_t)(b - 1) * RW;
+            for (uint32_t g = 0, b = b_hi; b > b_lo && !merged; g++) {
+                uint32_t bits = 0;
+                for (uint32_t r = 0; r < TE_RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * TE_BLK, st2);
+                uint32_t old_st[N], old_bits;
+                rec_load(g, old_st, old_bits);
                 merged = true;
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    if ((uint32_t)r[k] + size != st2[k]) merged = false;
-                    r[k] = (uint16_t)(st2[k] - size);
-                }
-                mybits += bits - (uint32_t)r[N];
-                r[N] = (uint16_t)bits;
+                for (int k = 0; k < N; k++) if (old_st[k] != st2[k]) merged = false;
+                mybits += bits - old_bits;
+                rec_store(g, st2, bits);
             }
             if (!merged) {                                   // ran to the end of the range (or owns no tokens): hand the states on
 #pragma unroll
