@@ -1029,8 +1029,13 @@ __global__ void __launch_bounds__(256) k_enc_pack(const MicUnit *units, const ui
     if (u.status != MICD_OK) return;
     const uint8_t *src = u.blob + (u.nstates_used == 1 ? 6 : 0);
     uint8_t *d = dst + dst_off[blockIdx.y];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < u.blob_len; i += gridDim.x * blockDim.x)
-        d[i] = src[i];
+    // 16 bytes per thread and step; neither side is aligned (gfx950 runs vector memory in unaligned mode)
+    typedef uint32_t pk_v4 __attribute__((ext_vector_type(4)));
+    typedef pk_v4 PkQ __attribute__((aligned(1)));
+    const uint32_t len = u.blob_len, nvec = len / 16;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x)
+        *(PkQ *)(d + (size_t)i * 16) = *(const PkQ *)(src + (size_t)i * 16);
+    if (blockIdx.x == 0 && threadIdx.x < (len & 15u)) d[nvec * 16 + threadIdx.x] = src[nvec * 16 + threadIdx.x];
 }
 
 // exclusive scan of blob lengths (single block; n units <= a few 100k)
