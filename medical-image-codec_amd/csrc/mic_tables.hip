@@ -482,24 +482,35 @@ __device__ void dec_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     if (tid == 0) { if (anybad) u.status = MICD_ERR_CORRUPT; u.zero_bits = anyzb ? 1u : 0u; }
 }
 
-__global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    __shared__ uint32_t s_misc[8];
+// Stream prefix + NCount parse (FSEDecompressU16Auto, fse2state.go:102-116; readNCount, fsedecompressu16.go:48-167).
+// The parse is a serial bit reader, so it gets a kernel of its own with one wave per unit: all units of a
+// launch parse side by side instead of one after the other under a 1024-thread group.  The head of the
+// blob is staged in LDS (the reader hops byte-wise); counts go to the unit's HBM norm[] slab.
+__global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DT_STAGE];
     MicUnit &u = units[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t len = u.comp_len;
-    uint8_t *s_in = s_raw + TB_OFF_VISIT;                                 // staged blob head; dead before the spread starts
-    int16_t *norm16 = (int16_t *)(s_raw + TB_OFF_NORM);
-    uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
-    if (u.comp_in) for (uint32_t i = tid; i < len && i < DT_STAGE; i += TP_THREADS) s_in[i] = u.comp_in[i];
+    if (u.comp_in) {
+        const uint32_t nst = min(len, (uint32_t)DT_STAGE);
+        const uint32_t head = (uint32_t)((16 - ((uintptr_t)u.comp_in & 15)) & 15);          // bytes up to 16-byte alignment
+        for (uint32_t i = tid; i < min(head, nst); i += 64) s_in[i] = u.comp_in[i];
+        if (nst > head) {
+            const uint32_t nvec = (nst - head) / 16;
+            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+            typedef v4 v4u __attribute__((aligned(1)));
+            for (uint32_t i = tid; i < nvec; i += 64) *(v4u *)(s_in + head + i * 16) = *(const v4 *)(u.comp_in + head + i * 16);
+            for (uint32_t i = head + nvec * 16 + tid; i < nst; i += 64) s_in[i] = u.comp_in[i];
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         u.status = MICD_OK; u.ntok = 0;
         int rc = MICD_OK;
-        uint32_t flavour = 1, count = 0, off = 0, used = 0, symbol_len = 0, tl = 0, small = 0;
+        uint32_t flavour = 1, count = 0, off = 0, used = 0, symbol_len = 0, tl = 0;
         do {
             if ((u.mode == 0 && (u.w <= 0 || u.h <= 0)) || !u.comp_in) { rc = MICD_ERR_ARGS; break; }
-            if (len >= 2 && s_in[0] == 0xFF) {                             // FSEDecompressU16Auto, fse2state.go:102-116
+            if (len >= 2 && s_in[0] == 0xFF) {
                 if (s_in[1] == 0x84) flavour = 8;
                 else if (s_in[1] == 0x08) flavour = 108;
                 else if (s_in[1] == 0x04) flavour = 4;
@@ -511,31 +522,33 @@ __global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
                 off = 6;
                 if (count > u.tok_cap) { rc = MICD_ERR_CORRUPT; break; }
             }
-            // Parse from the staged bytes into 16-bit LDS norm when that is certain to be identical:
-            // the whole blob is staged, or the header ends well inside the stage.
-            rc = MICD_ERR_UNSUPPORTED;
-            if (len <= DT_STAGE) rc = mic_read_ncount(s_in + off, len - off, norm16, &symbol_len, &tl, &used, TB_SMALL_SYMS);
+            // Parse from the staged bytes when that is certain to be identical: the whole blob is staged, or the
+            // header ends well inside the stage; otherwise from HBM.
+            if (len <= DT_STAGE) rc = mic_read_ncount(s_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
             else {
-                rc = mic_read_ncount(s_in + off, DT_STAGE - off, norm16, &symbol_len, &tl, &used, TB_SMALL_SYMS);
-                if (!(rc == MICD_OK && used + 8 < DT_STAGE - off)) rc = MICD_ERR_UNSUPPORTED;
-            }
-            if (rc == MICD_OK && tl <= TB_SMALL_TL) small = 1;
-            else if (rc == MICD_OK && tl > TB_SMALL_TL) {                  // widen into the HBM norm[] for the large path
-                for (uint32_t s = 0; s < symbol_len; s++) u.norm[s] = norm16[s];
-            } else {
-                rc = mic_read_ncount(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
+                rc = mic_read_ncount(s_in + off, DT_STAGE - off, u.norm, &symbol_len, &tl, &used, 65536u);
+                if (!(rc == MICD_OK && used + 8 < DT_STAGE - off))
+                    rc = mic_read_ncount(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
             }
         } while (0);
         if (rc == MICD_OK) { u.flavour = flavour; u.count = count; u.symbol_len = symbol_len; u.table_log = tl; u.bits_off = off + used; }
         else u.status = rc;
-        s_misc[0] = (uint32_t)rc; s_misc[1] = tl; s_misc[2] = symbol_len; s_misc[3] = flavour; s_misc[4] = small;
     }
-    __threadfence_block();
+}
+
+__global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    MicUnit &u = units[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (u.status != MICD_OK) return;                                      // k_dec_parse already failed this unit
+    int16_t *norm16 = (int16_t *)(s_raw + TB_OFF_NORM);
+    uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
+    const uint32_t tl = u.table_log, symbol_len = u.symbol_len, flavour = u.flavour;
+    const bool small = symbol_len <= TB_SMALL_SYMS && tl <= TB_SMALL_TL;
+    if (small) for (uint32_t s2 = tid; s2 < symbol_len; s2 += TP_THREADS) norm16[s2] = (int16_t)u.norm[s2];
     __syncthreads();
-    if ((int)s_misc[0] != MICD_OK) return;
-    const uint32_t tl = s_misc[1], symbol_len = s_misc[2], flavour = s_misc[3];
     uint32_t *bitmap = (uint32_t *)(s_raw + TB_OFF_BITMAP), *wprefix = (uint32_t *)(s_raw + TB_OFF_WPREF), *big = (uint32_t *)(s_raw + TB_OFF_BIG);
-    if (s_misc[4]) {
+    if (small) {
         dec_tables_body<int16_t, uint16_t>(u, norm16, (uint16_t *)(s_raw + TB_OFF_FIRST), (uint16_t *)(s_raw + TB_OFF_CUM),
                                            (uint16_t *)(s_raw + TB_OFF_VISIT), bitmap, wprefix, big, s_tmp, symbol_len, tl, flavour);
     } else {
@@ -553,5 +566,6 @@ void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream) {
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void *)k_dec_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); done = true; }
+    hipLaunchKernelGGL(k_dec_parse, dim3(n), dim3(64), 0, stream, d_units);
     hipLaunchKernelGGL(k_dec_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
 }
