@@ -381,7 +381,8 @@ __device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[16
 
 struct PrSlot {
     uint32_t d[16];       // 32 symbols
-    uint32_t raw;         // bit k: pixel k is stored raw
+    uint32_t w0, w1;      // flag words around the group (funnel-shifted at use: consuming them at fetch time would
+                          // make the fetch wait for its own loads)
     int32_t g, y;         // group and row; g < 0 or act == 0: nothing to do
     uint32_t p;           // pixel index of the group's first pixel
     uint32_t act;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
         s.g = cg; s.y = y;
         s.act = (cg >= 0 && cg < ngrp && cb < nb && y < H) ? 1u : 0u;
         s.p = (uint32_t)y * (uint32_t)W + (uint32_t)cg * PR_K;
-        s.raw = 0;
+        s.w0 = 0; s.w1 = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) s.d[i] = 0;
         if (s.act) {
@@ -457,9 +458,7 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
                     for (int i = 0; i < 16; i++) if (i == (k >> 1)) s.d[i] |= v << (16 * (k & 1));
                 }
             }
-            const uint32_t w0 = flags[s.p >> 5], w1 = flags[(s.p >> 5) + 1];
-            s.raw = __builtin_amdgcn_alignbit(w1, w0, s.p);      // bits of pixels p .. p+31
-            if (y == 0) s.raw = 0xFFFFFFFFu;                     // row 0 comes ready-made from the row buffer
+            s.w0 = flags[s.p >> 5]; s.w1 = flags[(s.p >> 5) + 1];
         }
         if (++cg == P) { cg = 0; cb++; }
     };
@@ -485,7 +484,10 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
         }
         uint32_t res[16];
         if (s.g == 0) left = top[0] & 0xFFFFu;                   // column 0: predictor = top ((top+top)>>1)
-        const bool any_raw = __any(s.act && s.raw != 0);
+        uint32_t raw = __builtin_amdgcn_alignbit(s.w1, s.w0, s.p);   // bit k: pixel p + k is stored raw
+        if (s.y == 0) raw = 0xFFFFFFFFu;                         // row 0 comes ready-made from the row buffer
+        if (!s.act) raw = 0;
+        const bool any_raw = __any(raw != 0);
         if (!any_raw) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -503,8 +505,8 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
                 const uint32_t src = row0 ? top[i] : s.d[i];
                 const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
                 const uint32_t v0 = src & 0xFFFFu, v1 = src >> 16;
-                const uint32_t r0 = ((s.raw >> (2 * i)) & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
-                const uint32_t r1 = ((s.raw >> (2 * i + 1)) & 1u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
+                const uint32_t r0 = ((raw >> (2 * i)) & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
+                const uint32_t r1 = ((raw >> (2 * i + 1)) & 1u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
                 res[i] = r0 | (r1 << 16);
                 left = r1;
             }
