@@ -131,6 +131,11 @@ int mic_hip_pics_decompress(const uint8_t *compressed, size_t compressed_len,
 int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nframes,
                           uint16_t max_value,
                           uint8_t *out, size_t out_cap, size_t *out_len);
+/* CompressMultiFrame(frames, w, h, maxValue, temporal=true) + WriteMIC2 (multiframecompress.go:179-224,
+ * temporaldelta.go:11-23): frame 0 spatial, frame i > 0 = RLE + FSE(2-state, 1-state fallback) of
+ * ZigZag(frame i - frame i-1).  Flags byte 0x03.  mic_hip_mic2_decompress reads both pipelines. */
+int mic_hip_mic2_compress_temporal(const uint16_t *frames, int width, int height, int nframes,
+                                   uint16_t max_value, uint8_t *out, size_t out_cap, size_t *out_len);
 int mic_hip_mic2_info(const uint8_t *compressed, size_t compressed_len,
                       int *width, int *height, int *nframes, int *temporal);
 /* Replaces DecompressMultiFrame (multiframecompress.go:227) for independent-mode files. */

@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "mic_hip_fse_compress_u16", "mic_hip_fse_decompress_u16_auto",
     "mic_hip_compress_batch", "mic_hip_decompress_batch",
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
-    "mic_hip_mic2_compress", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
+    "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level",
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
     L.mic_hip_pics_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
     L.mic_hip_mic2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint16,
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_mic2_compress_temporal.argtypes = L.mic_hip_mic2_compress.argtypes
     L.mic_hip_mic2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wavelet_v2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -284,15 +285,15 @@ def decompress_parallel_strips(compressed) -> Tuple[np.ndarray, int, int]:
 
 # ------------------------------------------------------------------ MIC2
 def compress_multi_frame(frames: np.ndarray, width: int, height: int, max_value: int, temporal: bool = False) -> bytes:
-    """CompressMultiFrame (multiframecompress.go:179), independent mode."""
-    if temporal:
-        raise MicError(MIC_ERR_UNSUPPORTED, "compress_multi_frame(temporal=True)")
+    """CompressMultiFrame (multiframecompress.go:179): independent frames, or the temporal pipeline
+    (frame 0 spatial, ZigZag residuals of consecutive frames after it)."""
     fr = _u16(frames)
     nframes = fr.shape[0]
     cap = fr.size * 2 + 4096 * (nframes + 1) + 8 * nframes + 20
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
-    rc = lib().mic_hip_mic2_compress(fr.ctypes.data, width, height, nframes, max_value, out.ctypes.data, cap, C.byref(n))
+    fn = lib().mic_hip_mic2_compress_temporal if temporal else lib().mic_hip_mic2_compress
+    rc = fn(fr.ctypes.data, width, height, nframes, max_value, out.ctypes.data, cap, C.byref(n))
     if rc:
         _raise(rc, "compress_multi_frame")
     return out[: n.value].tobytes()

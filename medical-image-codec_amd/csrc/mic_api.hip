@@ -499,6 +499,12 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     return MIC_OK;
 }
 
+int mic_hip_mic2_compress_temporal(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
+                                   uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!frames || !out || !out_len || width <= 0 || height <= 0 || nframes <= 0) return MIC_ERR_ARGS;
+    return mic2_temporal_compress(frames, width, height, nframes, max_value, out, out_cap, out_len);
+}
+
 int mic_hip_mic2_info(const uint8_t *c, size_t len, int *width, int *height, int *nframes, int *temporal) {
     if (!c) return MIC_ERR_ARGS;
     if (len < 20 || memcmp(c, "MIC2", 4) != 0) return MIC_ERR_CORRUPT;   // multiframe.go:96-103
@@ -513,10 +519,10 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     int w, h, n, temporal;
     int rc = mic_hip_mic2_info(c, len, &w, &h, &n, &temporal);
     if (rc) return rc;
-    if (temporal) return MIC_ERR_UNSUPPORTED;                            // temporal chain: SURVEY §8(f) "next"
     if (w <= 0 || h <= 0 || n <= 0) return MIC_ERR_CORRUPT;
     size_t npx = (size_t)w * (size_t)h;
     if (npx * (size_t)n > frames_cap_px) return MIC_ERR_CAPACITY;
+    if (temporal) return mic2_temporal_decompress(c, len, w, h, n, frames_out);   // mic_temporal.hip
     size_t data_off = 20 + (size_t)n * 8;
     std::vector<mic_hip_dec_job> jobs((size_t)n);
     for (int i = 0; i < n; i++) {

@@ -388,6 +388,8 @@ struct PrSlot {
     uint32_t act;
 };
 
+// WIDE names the row-buffer class of the launch (a distinct instantiation has its own line in a kernel trace).
+template <int WIDE>
 __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, int w_hi) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.mode != 0) return;
@@ -538,8 +540,8 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
     // two row-buffer classes so that ordinary widths keep many waves per CU
-    if (t) t->mark("k_dec_predict");
-    hipLaunchKernelGGL(k_dec_predict, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - PR_K);
+    if (t) t->mark("k_dec_predict<0>");
+    hipLaunchKernelGGL(k_dec_predict<0>, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - PR_K);
     if (t) t->mark("k_dec_predict<wide>");
-    hipLaunchKernelGGL(k_dec_predict, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, 8192 - PR_K, PR_MAX_W);
+    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, 8192 - PR_K, PR_MAX_W);
 }

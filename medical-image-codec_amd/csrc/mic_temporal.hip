@@ -1,0 +1,172 @@
+// mic_temporal.hip -- MIC2 with the temporal pipeline (flags 0x01 | 0x02).
+//
+// Reference: CompressMultiFrame(..., temporal=true) (multiframecompress.go:179-224): frame 0 is a
+// spatial frame; frame i > 0 is TemporalDeltaEncode(frame i, frame i-1) = ZigZag(cur - prev)
+// (temporaldelta.go:11-23) coded by compressResidualFrame = RleCompressU16 + FSE 2-state with the
+// 1-state fallback (multiframecompress.go:146-163).  DecompressMultiFrame (:227-261) inverts it frame by
+// frame.  Both directions are parallel over frames here: the encoder differences ORIGINAL frames, and on the
+// decode side  frame_i = frame_0 + sum_{j<=i} UnZigZag(res_j)  (mod 2^16) is a running sum along the frame
+// axis, so every residual stream is entropy-decoded at once and one kernel accumulates per pixel.
+#include <cstring>
+#include <vector>
+#include "../../include/mic_hip.h"
+#include "mic_session.h"
+#include "mic_launch.h"
+
+using namespace micapi;
+
+namespace {
+
+__device__ __forceinline__ uint32_t zigzag16(int32_t v) { const uint32_t x = (uint32_t)v & 0xFFFFu; return ((x << 1) ^ ((x & 0x8000u) ? 0xFFFFu : 0u)) & 0xFFFFu; }   // deltazigzagcompressu16.go:108-111
+__device__ __forceinline__ uint32_t unzigzag16(uint32_t u) { return ((u >> 1) ^ ((u & 1u) ? 0xFFFFu : 0u)) & 0xFFFFu; }                                            // :113-116
+
+// residual symbols of frames 1..n-1 into the units' symbol slabs, their maxima into dec_thr (free on the encode side)
+__global__ void __launch_bounds__(256) k_tmp_residual(MicUnit *units, const uint16_t *frames, uint32_t npx) {
+    MicUnit &u = units[blockIdx.y + 1];
+    const uint16_t *cur = frames + (size_t)(blockIdx.y + 1) * npx, *prev = cur - npx;
+    uint32_t m = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < npx; k += gridDim.x * blockDim.x) {
+        const uint32_t r = zigzag16((int32_t)cur[k] - (int32_t)prev[k]);
+        u.sym[k] = (uint16_t)r;
+        m = max(m, r);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&u.dec_thr, m);
+}
+__global__ void k_tmp_set_max(MicUnit *units, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n) units[i].max_value = (uint16_t)units[i].dec_thr;
+}
+
+// frame_i = frame_{i-1} + UnZigZag(res_i), all frames of one pixel by one thread
+__global__ void __launch_bounds__(256) k_tmp_accumulate(MicUnit *units, int n, uint16_t *frames, uint32_t npx) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < npx; k += gridDim.x * blockDim.x) {
+        uint32_t acc = frames[k];
+        for (int i = 1; i < n; i++) {
+            acc = (acc + unzigzag16(units[i].sym[k])) & 0xFFFFu;        // temporaldelta.go:27-37
+            frames[(size_t)i * npx + k] = (uint16_t)acc;
+        }
+    }
+}
+// residual streams must expand to exactly one frame (multiframecompress.go:170-172)
+__global__ void k_tmp_check(MicUnit *units, int n, uint32_t npx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n && units[i].status == MICD_OK && units[i].nsym != npx) units[i].status = MICD_ERR_CORRUPT;
+}
+
+inline void put_u32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+inline uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+}  // namespace
+
+void mic_launch_rle_expand(MicUnit *d_units, int n, hipStream_t stream, int mode_filter);   // mic_wavelet.hip
+
+namespace micapi {
+
+int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
+                           uint8_t *out, size_t out_cap, size_t *out_len) {
+    const size_t npx = (size_t)width * (size_t)height;
+    if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+    const size_t header = 20 + (size_t)nframes * 8;
+    if (out_cap < header) return MIC_ERR_CAPACITY;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if (unit_ws_bytes(npx) * (size_t)nframes > kWorkspaceBudget) return MIC_ERR_UNSUPPORTED;
+    if ((rc = s->io_px.reserve(npx * 2 * (size_t)nframes))) return rc;
+    if ((rc = s->ensure(nframes, npx))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->io_px.p, frames, npx * 2 * (size_t)nframes, hipMemcpyHostToDevice, s->stream));
+    s->h_units.assign((size_t)nframes, MicUnit{});
+    for (int i = 0; i < nframes; i++) {
+        MicUnit &u = s->h_units[(size_t)i];
+        u.w = width; u.h = height; u.nstates = 2;
+        s->fill_workspace(u, i);
+        u.tok_cap = (uint32_t)tok_cap_for(npx);
+        if (i == 0) { u.mode = 0; u.px_in = (const uint16_t *)s->io_px.p; u.max_value = max_value; }
+        else { u.mode = 2; u.nsym = (uint32_t)npx; u.max_value = 0; }
+    }
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nframes, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nframes, s->stream));
+    if (nframes > 1) {
+        const unsigned bx = (unsigned)std::min<size_t>((npx + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_tmp_residual, dim3(bx, (unsigned)(nframes - 1)), dim3(256), 0, s->stream,
+                           (MicUnit *)s->units.p, (const uint16_t *)s->io_px.p, (uint32_t)npx);
+        hipLaunchKernelGGL(k_tmp_set_max, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, s->stream, (MicUnit *)s->units.p, nframes);
+    }
+    s->timer.reset(s->stream);
+    mic_launch_encode((MicUnit *)s->units.p, nframes, s->stream, s->variant, nullptr);
+    HIP_TRY(hipGetLastError());
+    s->n_last = nframes;
+    std::vector<uint64_t> offs((size_t)nframes + 1);
+    std::vector<int32_t> st((size_t)nframes), ns((size_t)nframes);
+    const uint8_t *d_blobs = nullptr;
+    if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data()))) return rc;
+    for (int i = 0; i < nframes; i++) if (st[(size_t)i] != MIC_OK) return st[(size_t)i];
+    const uint64_t total = offs[(size_t)nframes];
+    if (total > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;              // u32 offsets, multiframe.go:75-80
+    if (out_cap < header + total) return MIC_ERR_CAPACITY;
+    memset(out, 0, header);
+    memcpy(out, "MIC2", 4);
+    put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height); put_u32(out + 12, (uint32_t)nframes);
+    out[16] = 0x01 | 0x02;                                              // PipelineSpatial | PipelineTemporal, multiframe.go:28-29
+    for (int i = 0; i < nframes; i++) {
+        put_u32(out + 20 + (size_t)i * 8, (uint32_t)offs[(size_t)i]);
+        put_u32(out + 24 + (size_t)i * 8, (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]));
+    }
+    if (total) HIP_TRY(hipMemcpy(out + header, d_blobs, (size_t)total, hipMemcpyDeviceToHost));
+    *out_len = header + (size_t)total;
+    return MIC_OK;
+}
+
+int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n, uint16_t *frames_out) {
+    const size_t npx = (size_t)w * (size_t)h;
+    if (npx > ((size_t)1 << 28) || len > 0xFFFFFFF0ull) return MIC_ERR_UNSUPPORTED;
+    const size_t data_off = 20 + (size_t)n * 8;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if (unit_ws_bytes(npx) * (size_t)n > kWorkspaceBudget) return MIC_ERR_UNSUPPORTED;
+    if ((rc = s->io_px.reserve(npx * 2 * (size_t)n))) return rc;
+    if ((rc = s->io_comp.reserve(len + 64))) return rc;
+    if ((rc = s->ensure(n, npx))) return rc;
+    s->h_units.assign((size_t)n, MicUnit{});
+    for (int i = 0; i < n; i++) {
+        const size_t start = data_off + get_u32(c + 20 + (size_t)i * 8), bl = get_u32(c + 24 + (size_t)i * 8);
+        if (start + bl > len) return MIC_ERR_CORRUPT;                     // multiframe.go:137-139
+        if (bl == 0) return MIC_ERR_CORRUPT;
+        MicUnit &u = s->h_units[(size_t)i];
+        u.comp_in = (const uint8_t *)s->io_comp.p + start; u.comp_len = (uint32_t)bl;
+        u.w = w; u.h = h;
+        s->fill_workspace(u, i);
+        u.tok_cap = (uint32_t)tok_cap_for(npx);
+        if (i == 0) { u.mode = 0; u.px_out = (uint16_t *)s->io_px.p; }
+        else u.mode = 3;                                                 // FSE + RLE-of-symbols into u.sym
+    }
+    HIP_TRY(hipMemcpyAsync(s->io_comp.p, c, len, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
+    s->timer.reset(s->stream);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr);
+    if (n > 1) {
+        mic_launch_rle_expand((MicUnit *)s->units.p, n, s->stream, 3);
+        hipLaunchKernelGGL(k_tmp_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (MicUnit *)s->units.p, n, (uint32_t)npx);
+    }
+    HIP_TRY(hipGetLastError());
+    s->n_last = n;
+    std::vector<int32_t> st((size_t)n);
+    if ((rc = session_decode_finish(s, st.data()))) return rc;
+    for (int i = 0; i < n; i++) if (st[(size_t)i] != MIC_OK) return st[(size_t)i];
+    if (n > 1) {
+        const unsigned bx = (unsigned)std::min<size_t>((npx + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_tmp_accumulate, dim3(bx), dim3(256), 0, s->stream, (MicUnit *)s->units.p, n, (uint16_t *)s->io_px.p, (uint32_t)npx);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(frames_out, s->io_px.p, npx * 2 * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return MIC_OK;
+}
+
+}  // namespace micapi

@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(WV_THREADS) k_wv_symbols(MicUnit *units, const
 
 // tokens -> symbols: RleDecompressU16.Init + Decompress (rledecompressu16.go:21-30, :87-97); header walk by
 // wave 0, expansion by all waves (as in mic_decode_px.hip), length taken from the two prefix words.
-__global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units) {
-    MicUnit &u = units[0];
+// One work-group per unit; mode_filter >= 0 restricts the launch to units of that mode (MIC2 temporal residuals).
+__global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units, int mode_filter) {
+    MicUnit &u = units[blockIdx.x];
+    if (mode_filter >= 0 && u.mode != (uint32_t)mode_filter) return;
     if (u.status != MICD_OK) return;
     __shared__ uint32_t s_misc[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -297,6 +299,10 @@ int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
 
 }  // namespace
 
+void mic_launch_rle_expand(MicUnit *d_units, int n, hipStream_t stream, int mode_filter) {
+    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)n), dim3(WV_THREADS), 0, stream, d_units, mode_filter);
+}
+
 extern "C" {
 
 // WaveletV2RLEFSECompressU16 / WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303, :374)
@@ -391,7 +397,7 @@ int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels
     if (hipMemsetAsync(A, 0, n * 4, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
     const WvDims d = wv_dims(rows, cols, levels);
-    hipLaunchKernelGGL(k_wv_expand, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p);
+    hipLaunchKernelGGL(k_wv_expand, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
     hipLaunchKernelGGL(k_wv_coeffs, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];

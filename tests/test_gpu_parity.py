@@ -144,6 +144,33 @@ def test_mic2_matches_oracle(mic, mico, synth, gpu_ready):
     assert np.array_equal(mic.decompress_multi_frame(got), stack)
 
 
+def test_mic2_temporal_matches_oracle(mic, mico, synth, gpu_ready):
+    """Temporal pipeline (multiframecompress.go:179-261): byte-identical container, both decoders agree, and the
+    GPU decodes what the oracle wrote."""
+    stack = synth.ct_stack(frames=7, size=128, depth=12, seed=33)
+    rc, want = mico.mic2_compress(stack, 4095, True)
+    assert rc == 0 and want[16] == 0x03
+    got = mic.compress_multi_frame(stack, 128, 128, 4095, temporal=True)
+    assert got == want
+    assert np.array_equal(mic.decompress_multi_frame(want), stack)
+    rc, back = mico.mic2_decompress(got)
+    assert rc == 0 and np.array_equal(np.asarray(back).reshape(stack.shape), stack)
+    # wrap-around residuals: a frame pair that differs by more than 32767
+    f0 = synth.xr_like(cols=160, rows=96, depth=12, seed=5).astype(np.int64)
+    n1 = (synth.hash_u64(96 * 160, 77) % np.uint64(41)).astype(np.int64).reshape(96, 160)
+    n2 = (synth.hash_u64(96 * 160, 78) % np.uint64(29)).astype(np.int64).reshape(96, 160)
+    f1 = (f0 + 40000 + n1) % 65536
+    big = np.stack([f0, f1, (f1 - 39000 + n2) % 65536]).astype(np.uint16)
+    rc, want = mico.mic2_compress(big, 65535, True)
+    assert rc == 0
+    got = mic.compress_multi_frame(big, 160, 96, 65535, temporal=True)
+    assert got == want
+    assert np.array_equal(mic.decompress_multi_frame(got), big)
+    # truncated residual stream
+    with pytest.raises(mic.MicError):
+        mic.decompress_multi_frame(want[:-3])
+
+
 def test_batch_mixed_shapes(mic, mico, synth, gpu_ready):
     """One batch, ragged shapes; tiny noisy frames fail in the oracle (normaliser error) and
     must fail with the same code on the GPU."""
