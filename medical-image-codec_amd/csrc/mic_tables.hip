@@ -50,14 +50,21 @@ __device__ __forceinline__ uint32_t tb_wave_max(uint32_t v) {
 //   largest power of two <= remaining (at most 2^tl), nbBits = log2(threshold) + 1,
 //   max = 2*threshold - 1 - remaining, v = count + 1 (+ max when v >= threshold), nbBits - 1 bits when v < max.
 // Bit offsets are a second prefix sum; fields are OR-ed into an LDS bit buffer and copied out.
-// rem16 / s016: symbol_len u16 each, bitbuf: zero-initialised here, ((symbol_len * tl) >> 3) + 8 bytes.
-__device__ int tb_write_ncount_par(const int16_t *norm, uint32_t symbol_len, uint32_t tl, uint16_t *rem16, uint16_t *s016,
-                                   uint32_t *bitbuf, uint32_t *s_tmp, uint8_t *out, uint32_t cap, uint32_t *hdr_len) {
+// rem16 / s016: symbol_len entries each; bitbuf: zero-initialised here, bit_base + 8 * (((symbol_len * tl) >> 3) + 8) bits.
+// Small alphabets: everything in LDS, the finished header is copied to `out`.  Large ones (HBM scratch): bitbuf is
+// the output itself, addressed from the aligned word 2 bytes in front of it (bit_base = 16, to_out = false).
+// For tableLog 16 a count field can be 17 bits; the reference's 32-bit accumulator holds 16 pending bits at
+// most when a field arrives, so a field that would not fit (pending + length > 32) makes this return
+// MICD_ERR_UNSUPPORTED and the caller runs the serial writer, which reproduces the wrap (fsecompressu16.go:260-262).
+template <typename NormT, typename ScrT>
+__device__ int tb_write_ncount_par(const NormT *norm, uint32_t symbol_len, uint32_t tl, ScrT *rem16, ScrT *s016,
+                                   uint32_t *bitbuf, uint32_t bit_base, bool to_out, uint32_t *s_tmp, uint8_t *out, uint32_t cap,
+                                   uint32_t *hdr_len) {
     const uint32_t tid = threadIdx.x;
     const uint32_t size = 1u << tl;
     const uint32_t max_header = ((symbol_len * tl) >> 3) + 3;
     if (cap < max_header + 2) return MICD_ERR_CAPACITY;
-    const uint32_t nwords = (max_header + 8 + 3) / 4;
+    const uint32_t nwords = (bit_base / 8 + max_header + 8 + 3) / 4;
     for (uint32_t i = tid; i < nwords; i += TP_THREADS) bitbuf[i] = 0;
     // pass A: remaining in front of every symbol, first zero of the run a symbol closes
     uint32_t carry_sum = 0, carry_fz = 0;
@@ -80,14 +87,14 @@ __device__ int tb_write_ncount_par(const int16_t *norm, uint32_t symbol_len, uin
         uint32_t mtot = carry_fz;
         for (uint32_t w = 0; w < TP_WAVES; w++) { const uint32_t x = s_tmp[32 + w]; if (w < wave) me = max(me, x); mtot = max(mtot, x); }
         me = max(me, carry_fz);
-        if (s2 < symbol_len) { rem16[s2] = (uint16_t)(size + 1 - (carry_sum + ex)); s016[s2] = (uint16_t)me; }
+        if (s2 < symbol_len) { rem16[s2] = (ScrT)(size + 1 - (carry_sum + ex)); s016[s2] = (ScrT)me; }
         carry_sum += tot; carry_fz = mtot;
     }
     if (carry_sum != size) return MICD_ERR_INTERNAL;          // (the serial writer ends with remaining != 1)
     __syncthreads();
     // field of symbol s: ones (run code body), then `lo` = [2-bit run remainder][count field] in lo_len bits
-    auto field = [&](uint32_t s2, uint32_t &ones, uint32_t &lo, uint32_t &lo_len) {
-        ones = 0; lo = 0; lo_len = 0;
+    auto field = [&](uint32_t s2, uint32_t &ones, uint64_t &lo, uint32_t &lo_len, uint32_t &flen_out) {
+        ones = 0; lo = 0; lo_len = 0; flen_out = 0;
         const int32_t v = (int32_t)norm[s2];
         const int32_t vp = s2 > 0 ? (int32_t)norm[s2 - 1] : 1;
         if (v == 0 && vp == 0) return;                                    // inside a zero run: part of the run code
@@ -105,18 +112,23 @@ __device__ int tb_write_ncount_par(const int16_t *norm, uint32_t symbol_len, uin
         int32_t cnt = v + 1;
         if (cnt >= threshold) cnt += mx;
         const uint32_t flen = nbb - ((cnt < mx) ? 1u : 0u);
-        lo |= (uint32_t)cnt << lo_len; lo_len += flen;
+        lo |= (uint64_t)(uint32_t)cnt << lo_len; lo_len += flen; flen_out = flen;
     };
     // pass B: offsets and packing
-    uint32_t carry_bits = 4;
-    if (tid == 0) atomicOr(&bitbuf[0], tl - MIC_MIN_TABLELOG);
+    uint32_t carry_bits = bit_base + 4;
+    uint32_t wraps = 0;
+    if (tid == 0) atomicOr(&bitbuf[bit_base >> 5], (tl - MIC_MIN_TABLELOG) << (bit_base & 31));
     for (uint32_t base = 0; base < symbol_len; base += TP_THREADS) {
         const uint32_t s2 = base + tid;
-        uint32_t ones = 0, lo = 0, lo_len = 0;
-        if (s2 < symbol_len) field(s2, ones, lo, lo_len);
+        uint32_t ones = 0, lo_len = 0, flen = 0; uint64_t lo = 0;
+        if (s2 < symbol_len) field(s2, ones, lo, lo_len, flen);
         uint32_t tot;
         const uint32_t ex = tp_block_excl(ones + lo_len, s_tmp, &tot);
         uint32_t pos = carry_bits + ex;
+        if (tl > 15 && flen) {                                            // pending bits when the count field arrives: 1 .. 16
+            const uint32_t tb = pos - bit_base + ones + (lo_len - flen);
+            if (((tb - 1) & 15u) + 1 + flen > 32) wraps = 1;
+        }
         if (ones) {                                                       // bits [pos, pos + ones) set
             uint32_t left = ones;
             while (left) {
@@ -126,18 +138,22 @@ __device__ int tb_write_ncount_par(const int16_t *norm, uint32_t symbol_len, uin
                 pos += take; left -= take;
             }
         }
-        if (lo_len) {
+        if (lo_len) {                                                     // <= 19 bits
             const uint32_t sh = pos & 31;
-            atomicOr(&bitbuf[pos >> 5], lo << sh);
-            if (sh + lo_len > 32) atomicOr(&bitbuf[(pos >> 5) + 1], lo >> (32 - sh));
+            const uint64_t v = lo << sh;
+            atomicOr(&bitbuf[pos >> 5], (uint32_t)v);
+            if (sh + lo_len > 32) atomicOr(&bitbuf[(pos >> 5) + 1], (uint32_t)(v >> 32));
         }
         carry_bits += tot;
     }
-    __syncthreads();
-    const uint32_t nbytes = (carry_bits + 7) >> 3;
+    if (__syncthreads_or((int)wraps)) return MICD_ERR_UNSUPPORTED;
+    const uint32_t nbytes = (carry_bits - bit_base + 7) >> 3;
     if (nbytes > max_header) return MICD_ERR_INTERNAL;
-    const uint8_t *bb = (const uint8_t *)bitbuf;
-    for (uint32_t i = tid; i < nbytes + 8; i += TP_THREADS) out[i] = (i < nbytes) ? bb[i] : (uint8_t)0;   // + the 8 bytes k_enc_tans_wg ORs into
+    if (to_out) {
+        const uint8_t *bb = (const uint8_t *)bitbuf + bit_base / 8;
+        for (uint32_t i = tid; i < nbytes + 8; i += TP_THREADS) out[i] = (i < nbytes) ? bb[i] : (uint8_t)0;   // + the 8 bytes k_enc_tans_wg ORs into
+    }
+    __threadfence_block();
     *hdr_len = nbytes;
     return MICD_OK;
 }
@@ -301,12 +317,21 @@ __device__ void enc_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
     __syncthreads();
     MIC_STAMP_AT(u, 5);
     // ---- NCount header (one lane; fsecompressu16.go:191-289) ----------------------------------------
-    if (sizeof(NormT) == 2 && tl <= 14 && u.blob_cap >= 6 + 16) {
-        // LDS scratch that tp_build only needs later: first_visit / cum_all hold the two u16 arrays, visit_pos the bit buffer
+    int rc_par = MICD_ERR_UNSUPPORTED;
+    if (u.blob_cap >= 6 + 16 && ((uintptr_t)u.blob & 3) == 0) {
+        // scratch that tp_build only needs later: first_visit / cum_all hold the two per-symbol arrays; small alphabets
+        // pack into visit_pos (LDS) and copy out, large ones pack straight into the blob (word-aligned 2 bytes ahead)
         uint32_t hdr = 0;
-        const int rc = tb_write_ncount_par((const int16_t *)norm, symbol_len, tl, (uint16_t *)first_visit, (uint16_t *)cum_all,
-                                           (uint32_t *)visit_pos, s_tmp, u.blob + 6, u.blob_cap - 6 - 8, &hdr);
-        if (tid == 0) { if (rc == MICD_OK) u.hdr_len = hdr; s_misc[3] = (uint32_t)rc; }
+        if (sizeof(NormT) == 2)
+            rc_par = tb_write_ncount_par(norm, symbol_len, tl, first_visit, cum_all, (uint32_t *)visit_pos, 0u, true, s_tmp,
+                                         u.blob + 6, u.blob_cap - 6 - 8, &hdr);
+        else
+            rc_par = tb_write_ncount_par(norm, symbol_len, tl, first_visit, cum_all, (uint32_t *)(u.blob + 4), 16u, false, s_tmp,
+                                         u.blob + 6, u.blob_cap - 6 - 8, &hdr);
+        if (rc_par != MICD_ERR_UNSUPPORTED && tid == 0) { if (rc_par == MICD_OK) u.hdr_len = hdr; s_misc[3] = (uint32_t)rc_par; }
+        __syncthreads();
+    }
+    if (rc_par != MICD_ERR_UNSUPPORTED) {
     } else if (tid == 0) {
         int rc = MICD_OK;
         uint32_t hdr = 0;
