@@ -260,7 +260,8 @@ __device__ inline uint32_t mic_rd_u32(const uint8_t *b, uint32_t len, int64_t of
 // fsedecompressu16.go:48-167 (readNCount); single lane.  b/len = stream after the prefix.
 // norm_cap: entries available in norm[]; MICD_ERR_UNSUPPORTED when the alphabet is larger (the
 // caller then parses again into the full 65536-entry array).
-template <typename NormT>
+// PREZEROED: norm[] is all zero on entry, so zero-runs only move the symbol cursor.
+template <typename NormT, bool PREZEROED = false>
 __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *norm,
                                       uint32_t *symbol_len_out, uint32_t *tl_out, uint32_t *consumed,
                                       uint32_t norm_cap) {
@@ -298,7 +299,8 @@ __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *nor
             bit_count += 2;
             if (n0 > MIC_MAXSYM) return MICD_ERR_CORRUPT;
             if (n0 > norm_cap) return MICD_ERR_UNSUPPORTED;
-            while (charnum < n0) { norm[charnum & 0xffff] = 0; charnum++; }
+            if (PREZEROED) charnum = max(charnum, n0);
+            else while (charnum < n0) { norm[charnum & 0xffff] = 0; charnum++; }
             if (off <= iend - 7 || off + (int64_t)(bit_count >> 3) <= iend - 4) {
                 off += (int64_t)(bit_count >> 3);
                 bit_count &= 7;

@@ -511,13 +511,23 @@ __device__ void dec_tables_body(MicUnit &u, NormT *norm, IdxT *first_visit, IdxT
 // The parse is a serial bit reader, so it gets a kernel of its own with one wave per unit: all units of a
 // launch parse side by side instead of one after the other under a 1024-thread group.  The head of the
 // blob is staged in LDS (the reader hops byte-wise); counts go to the unit's HBM norm[] slab.
+// Two classes: BIG = false stages 8 KiB and handles alphabets up to 8192 symbols (every depth <= 13: many groups per
+// CU, 32 KiB of counts to clear); what it cannot take -- a longer header, a larger alphabet: 16-bit-depth frames --
+// it leaves marked for BIG = true (40 KiB stage, all 65536 counts cleared).
+#define DP_DEFER 0xDEFE7u      // in u.flavour: parse left to the BIG class
+template <bool BIG>
 __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DT_STAGE];
+    constexpr uint32_t DP_STAGE = BIG ? 40u * 1024u : 8u * 1024u;
+    constexpr uint32_t DP_SYMS = BIG ? 65536u : 8192u;
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DP_STAGE];
     MicUnit &u = units[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t len = u.comp_len;
+    if (BIG && u.flavour != DP_DEFER) return;
+    // the counts array starts out zero (the zero-runs of the header then cost nothing but a cursor move)
+    if (u.norm) { uint4 *z = (uint4 *)u.norm; for (uint32_t i = tid; i < DP_SYMS / 4; i += 64) z[i] = make_uint4(0, 0, 0, 0); }
     if (u.comp_in) {
-        const uint32_t nst = min(len, (uint32_t)DT_STAGE);
+        const uint32_t nst = min(len, (uint32_t)DP_STAGE);
         const uint32_t head = (uint32_t)((16 - ((uintptr_t)u.comp_in & 15)) & 15);          // bytes up to 16-byte alignment
         for (uint32_t i = tid; i < min(head, nst); i += 64) s_in[i] = u.comp_in[i];
         if (nst > head) {
@@ -549,13 +559,19 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
             }
             // Parse from the staged bytes when that is certain to be identical: the whole blob is staged, or the
             // header ends well inside the stage; otherwise from HBM.
-            if (len <= DT_STAGE) rc = mic_read_ncount(s_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
+            if (len <= DP_STAGE) rc = mic_read_ncount<int32_t, true>(s_in + off, len - off, u.norm, &symbol_len, &tl, &used, DP_SYMS);
             else {
-                rc = mic_read_ncount(s_in + off, DT_STAGE - off, u.norm, &symbol_len, &tl, &used, 65536u);
-                if (!(rc == MICD_OK && used + 8 < DT_STAGE - off))
-                    rc = mic_read_ncount(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
+                rc = mic_read_ncount<int32_t, true>(s_in + off, DP_STAGE - off, u.norm, &symbol_len, &tl, &used, DP_SYMS);
+                if (!(rc == MICD_OK && used + 8 < DP_STAGE - off)) {
+                    if (!BIG) rc = MICD_ERR_UNSUPPORTED;
+                    else {
+                        for (uint32_t i = 0; i < 65536; i++) u.norm[i] = 0;    // (rare: header longer than the stage) start over from HBM
+                        rc = mic_read_ncount<int32_t, true>(u.comp_in + off, len - off, u.norm, &symbol_len, &tl, &used, 65536u);
+                    }
+                }
             }
         } while (0);
+        if (!BIG && rc == MICD_ERR_UNSUPPORTED) { u.flavour = DP_DEFER; return; }
         if (rc == MICD_OK) { u.flavour = flavour; u.count = count; u.symbol_len = symbol_len; u.table_log = tl; u.bits_off = off + used; }
         else u.status = rc;
     }
@@ -591,6 +607,7 @@ void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream) {
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void *)k_dec_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); done = true; }
-    hipLaunchKernelGGL(k_dec_parse, dim3(n), dim3(64), 0, stream, d_units);
+    hipLaunchKernelGGL(k_dec_parse<false>, dim3(n), dim3(64), 0, stream, d_units);
+    hipLaunchKernelGGL(k_dec_parse<true>, dim3(n), dim3(64), 0, stream, d_units);
     hipLaunchKernelGGL(k_dec_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
 }
