@@ -41,7 +41,8 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t g, uint32_t f) {
     return ((g >> (f & 1)) & 1) | (((g >> ((f >> 1) & 1)) & 1) << 1);
 }
 
-__global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
+// 8 waves per SIMD (= two groups per CU): keeps the kernel under 96 SGPRs and 64 VGPRs, which it nearly is anyway
+__global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.mode != 0) return;
     __shared__ uint32_t s_fn[PX_WAVES + 1];
@@ -108,70 +109,100 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
         uint32_t carry_state = 0;        // marker state of the symbol in front of the tile
         uint32_t carry_px = 0;           // pixels numbered so far
         uint32_t s_lo = 0;               // first segment that reaches into the tile
+        uint32_t tab_r0 = 0; bool tab_ok = false;   // segment index of the LDS table's first entry
+        // this thread's 8 symbols [i0, wend) out of the LDS segment table (entries from segment r0 on): gallop from
+        // table index j0, bisect, then one 16-byte load when the window lies inside one literal segment
+        typedef uint32_t px_v4 __attribute__((ext_vector_type(4)));
+        typedef px_v4 PxQ __attribute__((aligned(2)));
+        auto fetch8 = [&](uint32_t i0, uint32_t wend, uint32_t j0, uint32_t (&w8)[4], uint32_t &bad, uint32_t &jout) {
+            uint32_t j = j0, stp = 16;
+            while (j + stp <= PX_THREADS && s_segy[j + stp] <= i0) { j += stp; stp <<= 1; }
+            for (stp >>= 1; stp; stp >>= 1) if (j + stp <= PX_THREADS && s_segy[j + stp] <= i0) j += stp;
+            uint32_t start = s_segy[j], endj = min(s_segy[j + 1], nsym), sx = s_segx[j];
+            w8[0] = w8[1] = w8[2] = w8[3] = 0;
+            if (wend - i0 == PX_SPT && i0 + PX_SPT <= endj) {
+                const uint32_t xs = sx & 0x7FFFFFFFu;
+                if (sx >> 31) {                                           // same-run: one value
+                    const uint32_t v = tok[xs];
+                    w8[0] = w8[1] = w8[2] = w8[3] = v | (v << 16);
+                } else {
+                    const uint32_t src = xs + (i0 - start);
+                    if (src + PX_SPT <= ntok) {
+                        const px_v4 v = *(const PxQ *)(tok + src);
+                        w8[0] = v.x; w8[1] = v.y; w8[2] = v.z; w8[3] = v.w;
+                    } else bad = 1;                                       // literal run past the end (Go: index panic)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PX_SPT; k++) {
+                    const uint32_t i = i0 + k;
+                    if (i < wend) {
+                        while (i >= endj) { j++; start = s_segy[j]; endj = min(s_segy[j + 1], nsym); sx = s_segx[j]; }
+                        const uint32_t xs = sx & 0x7FFFFFFFu;
+                        const uint32_t src = (sx >> 31) ? xs : xs + (i - start);
+                        if (src < ntok) w8[k >> 1] |= (uint32_t)tok[src] << (16 * (k & 1)); else bad = 1;
+                    }
+                }
+            }
+            jout = j;
+        };
+        // symbols of the NEXT tile, fetched while this one is scanned (valid when the table covered that tile)
+        bool pre_cov = false; uint32_t p8[4] = { 0u, 0u, 0u, 0u }; uint32_t pre_bad = 0, pre_j = 0;
+        MIC_STAMP_BEGIN();
         for (uint32_t base = 0; base < nsym && carry_px < npx; base += PX_T) {
             const uint32_t tile_end = min(base + PX_T, nsym);
             // (a) every thread fetches its 8 consecutive symbols straight from the token stream.  The tile's
-            // segments (start symbol, payload position, run flag) are staged in LDS PX_THREADS at a time;
-            // a thread finds its segment by binary search and, when its 8 symbols lie inside one segment
-            // (the usual case: literal chunks are ~2^depth long), takes them with one 16-byte load.
+            // segments (start symbol, payload position | run flag) sit in an LDS table of PX_THREADS entries that
+            // persists across tiles (it usually covers dozens of them) and is reloaded only when a tile reaches past
+            // it; reload rounds overlap by 8 segments (a window of 8 symbols spans at most 8).
             const uint32_t i0 = base + tid * PX_SPT;
             const uint32_t wend = min(i0 + PX_SPT, tile_end);            // this thread's symbols are [i0, wend)
             uint32_t w8[4] = { 0u, 0u, 0u, 0u };
             bool got = i0 >= tile_end;
-            for (uint32_t r0 = s_lo;; r0 += PX_THREADS - PX_SPT) {         // rounds overlap by 8 segments: a window spans at most 8
-                {
-                    const uint32_t si = r0 + tid;
-                    uint2 sg = make_uint2(0u, 0xFFFFFFFFu);
-                    if (si < nseg) sg = seg[si];
-                    s_segx[tid] = sg.x; s_segy[tid] = sg.y;
-                    if (tid == 0) { const uint32_t sj = r0 + PX_THREADS; s_segy[PX_THREADS] = (sj < nseg) ? seg[sj].y : 0xFFFFFFFFu; s_misc[4] = 0; }
+            uint32_t my_seg = s_lo;                                      // segment this thread found (absolute index; hint for the next tile)
+            if (pre_cov) {
+                if (!got) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w8[k] = p8[k];
+                    if (pre_bad) s_misc[3] = 1;
+                    if (wend == tile_end) s_misc[5] = tab_r0 + pre_j;
+                    my_seg = tab_r0 + pre_j; got = true;
                 }
-                __syncthreads();
-                if (s_segy[tid] < tile_end && s_segy[tid + 1] >= tile_end) s_misc[4] = tid + 1;   // sorted: one writer at most
-                __syncthreads();
-                const uint32_t cover_end = s_segy[PX_THREADS];           // first symbol this round's segments do not cover
-                const uint32_t cnt = (cover_end < tile_end) ? (uint32_t)PX_THREADS : s_misc[4];
-                if (!got && s_segy[0] <= i0 && wend <= cover_end) {
-                    uint32_t j = 0;
-                    for (uint32_t stp = (cnt > 1) ? (1u << (31 - __clz(cnt - 1))) : 0u; stp; stp >>= 1)
-                        if (s_segy[j + stp] <= i0) j += stp;
-                    uint32_t start = s_segy[j], endj = min(s_segy[j + 1], nsym), sx = s_segx[j];
-                    uint32_t bad = 0;
-                    if (wend - i0 == PX_SPT && i0 + PX_SPT <= endj) {
-                        const uint32_t xs = sx & 0x7FFFFFFFu;
-                        if (sx >> 31) {                                   // same-run: one value
-                            const uint32_t v = tok[xs];
-                            w8[0] = w8[1] = w8[2] = w8[3] = v | (v << 16);
-                        } else {
-                            const uint32_t src = xs + (i0 - start);
-                            if (src + PX_SPT <= ntok) {
-                                const PxVec v = *(const PxVec *)(tok + src);
-#pragma unroll
-                                for (int k = 0; k < PX_SPT; k++) w8[k >> 1] |= (uint32_t)v.v[k] << (16 * (k & 1));
-                            } else bad = 1;
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < PX_SPT; k++) {
-                            const uint32_t i = i0 + k;
-                            if (i < wend) {
-                                while (i >= endj) { j++; start = s_segy[j]; endj = min(s_segy[j + 1], nsym); sx = s_segx[j]; }
-                                const uint32_t xs = sx & 0x7FFFFFFFu;
-                                const uint32_t src = (sx >> 31) ? xs : xs + (i - start);
-                                if (src < ntok) w8[k >> 1] |= (uint32_t)tok[src] << (16 * (k & 1)); else bad = 1;
-                            }
-                        }
+            } else {
+                for (uint32_t r0 = tab_ok ? tab_r0 : s_lo;; r0 += PX_THREADS - PX_SPT) {
+                    if (!(tab_ok && r0 == tab_r0)) {
+                        __syncthreads();                                     // every reader of the old table is done
+                        const uint32_t si = r0 + tid;
+                        uint2 sg = make_uint2(0u, 0xFFFFFFFFu);
+                        if (si < nseg) sg = seg[si];
+                        s_segx[tid] = sg.x; s_segy[tid] = sg.y;
+                        if (tid == 0) { const uint32_t sj = r0 + PX_THREADS; s_segy[PX_THREADS] = (sj < nseg) ? seg[sj].y : 0xFFFFFFFFu; }
+                        __syncthreads();
+                        tab_r0 = r0; tab_ok = true;
                     }
-                    if (bad) s_misc[3] = 1;                              // literal run past the end (Go: index panic)
-                    if (wend == tile_end) s_misc[5] = r0 + j;            // segment of the tile's last symbol: where the next tile starts
-                    got = true;
+                    const uint32_t cover_end = s_segy[PX_THREADS];       // first symbol this table's segments do not cover
+                    if (!got && s_segy[0] <= i0 && wend <= cover_end) {
+                        uint32_t bad = 0, j;
+                        fetch8(i0, wend, (s_lo > r0) ? s_lo - r0 : 0u, w8, bad, j);
+                        if (bad) s_misc[3] = 1;
+                        if (wend == tile_end) s_misc[5] = r0 + j;        // segment of the tile's last symbol: where the next tile starts
+                        my_seg = r0 + j; got = true;
+                    }
+                    if (!(cover_end < tile_end)) break;
                 }
-                const bool more = cover_end < tile_end;
-                __syncthreads();
-                if (!more) break;
             }
-            s_lo = s_misc[5];
-            if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+            {   // prefetch for the next tile, if the table in LDS already covers it
+                const uint32_t base2 = base + PX_T;
+                const uint32_t tile_end2 = min(base2 + PX_T, nsym);
+                pre_cov = base2 < nsym && s_segy[PX_THREADS] >= tile_end2;   // uniform
+                if (pre_cov) {
+                    const uint32_t i2 = base2 + tid * PX_SPT, wend2 = min(i2 + PX_SPT, tile_end2);
+                    const uint32_t j0 = (my_seg > tab_r0) ? my_seg - tab_r0 : 0u;   // (the table may have been reloaded since)
+                    pre_bad = 0; pre_j = j0;
+                    if (i2 < tile_end2) fetch8(i2, wend2, j0, p8, pre_bad, pre_j);
+                }
+            }
+            MIC_STAMP_AT(u, 0);
             // (b) marker[i] = isDelim[i] & !marker[i-1], a pixel = a non-marker symbol.
             // One scan carries, for both possible entry states, the exit state and the pixel count:
             //   t = s0 | s1 << 1 | c0 << 2 | c1 << 16
@@ -214,6 +245,9 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
             uint32_t excl = __shfl_up(incl, 1);
             if (lane == 0) excl = 2u;                                    // identity: s0 = 0, s1 = 1, no pixels
             __syncthreads();
+            MIC_STAMP_AT(u, 1);
+            s_lo = s_misc[5];                                            // (this barrier also publishes the fetch phase's verdicts)
+            if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
             // entry (state, pixel count) of this wave and exit of the tile, from the 16 wave totals
             uint32_t st_w = carry_state, cnt_w = 0, st_all, cnt_all;
             {
@@ -242,6 +276,7 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
                 st_in = m;
             }
             __syncthreads();
+            MIC_STAMP_AT(u, 2);
             // (c) the tile's pixels leave as 16-byte vectors (2-byte aligned destination)
             {
                 const uint32_t n_out = min(cnt_all, npx - carry_px);
@@ -252,6 +287,7 @@ __global__ void __launch_bounds__(PX_THREADS) k_dec_pixels_wg(MicUnit *units) {
             carry_px += cnt_all;
             carry_state = st_all;
             __syncthreads();
+            MIC_STAMP_AT(u, 3);
         }
         if (carry_px < npx) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }   // tokens ran out (Go: panic)
     }
