@@ -130,14 +130,14 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 //     the whole stream never open a chunk.
 // Every symbol can therefore compute the tokens it is responsible for from x[i-3..i+3], its
 // index inside its run / stretch (segmented max-scans) and a prefix sum of token counts.
-// A tile is 4096 pixels: their symbols (1 or 2 per pixel, prefix-summed only when the tile holds
+// A tile is 2048 pixels: their symbols (1 or 2 per pixel, prefix-summed only when the tile holds
 // an escape) go into an LDS window and are tokenised with a delay of 3 symbols so the look-ahead
 // is always present.  A thread owns 8 consecutive window positions; the equality pattern of its
 // 14-symbol neighbourhood is one bit mask and "in a same-run", "run start", "stretch start",
 // "run end" are shifts and ANDs of it; run / stretch indices modulo c advance incrementally from
 // one multiply-high reduction per thread and tile.
-#define TK_THREADS 1024
-#define TK_WAVES 16
+#define TK_THREADS 512              // two groups per CU (128 VGPRs each): one group's barriers overlap the other's work
+#define TK_WAVES 8
 #define TK_PPT 4
 #define TK_SPT 8
 #define TK_WIN (TK_THREADS * TK_SPT)
@@ -181,10 +181,10 @@ typedef tk_v2 TkD __attribute__((aligned(2)));                 // 4 pixels, 2-by
 // SRC 1: RLE-of-symbols units (mode 2, wavelet / residual paths) -- RleCompressU16.Init(len,1,max).Compress(symbols)
 //        (rlecompressu16.go:85-93): symbols come from u.sym[0..u.nsym), stream = [max][len>>16][len&0xFFFF][RLE(symbols)].
 template <int SRC>
-__global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
+__global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per tile parity: [0..5] = 6 symbols before the tile, [6..] = new symbols
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TK_WAVES], s_run[TK_WAVES], s_str[TK_WAVES], s_tc[TK_WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16], s_run[16], s_str[16], s_tc[16];   // per-wave partials (unused tail stays 0)
     __shared__ uint32_t s_ovf, s_last[2];
     // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
     // the delta threshold takes almost every token; the rest goes to HBM atomics
@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(TK_THREADS) k_enc_tokens_wg(MicUnit *units) {
     uint32_t *ghist = u.hist;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
     for (uint32_t i = tid; i < 2 * (TK_WIN + 16); i += TK_THREADS) (&xs2[0][0])[i] = 0;
+    if (tid < 16) { s_cnt[tid] = 0; s_run[tid] = 0; s_str[tid] = 0; s_tc[tid] = 0; }
     __syncthreads();
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
