@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_WAVES 16
 #define TE_BLK 32                 // tokens per 64-byte block
 #define TE_RGRP 4                 // blocks per fix-up record
+#define TE_WARM 4                 // blocks of the predecessor's range walked as warm-up
 #define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
 
 // One block of 32 tokens / 32 recorded states as four 16-byte vectors.
@@ -817,6 +818,15 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     uint32_t st[N];
 #pragma unroll
     for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
+    // Warm-up: walks merge within ~100 symbols, so walking the last TE_WARM blocks of the predecessor's range first
+    // (nothing recorded) almost always lands on the true start state, and the fix-up below only has to confirm it.
+    if (tid > 0 && b_hi > b_lo) {
+        const uint32_t w_hi = min(b_hi + TE_WARM, nblk);
+        for (uint32_t b = w_hi; b > b_hi; b--) (void)walk_block((b - 1) * TE_BLK, st);
+    }
+    uint32_t assumed[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) assumed[k] = st[k];
     uint32_t mybits = 0;
     for (uint32_t g = 0, b = b_hi; b > b_lo; g++) {
         uint32_t bits = 0;
@@ -826,9 +836,6 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     }
 #pragma unroll
     for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
-    uint32_t assumed[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) assumed[k] = size;
     MIC_STAMP_AT(u, 8);
     // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
     for (uint32_t round = 0; round < TE_THREADS; round++) {
@@ -844,7 +851,13 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         }
         if (any) {
             bool merged = false;
+#ifdef MIC_STAMP
+            atomicAdd(&u.dbg[13], 1u);                                    // threads that re-walk, all rounds
+#endif
             for (uint32_t g = 0, b = b_hi; b > b_lo && !merged; g++) {
+#ifdef MIC_STAMP
+                atomicMax(&u.dbg[14], g + 1);                             // longest re-walk in groups
+#endif
                 uint32_t bits = 0;
                 for (uint32_t r = 0; r < TE_RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * TE_BLK, st2);
                 uint32_t old_st[N], old_bits;
@@ -863,6 +876,9 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         __syncthreads();                                   // every thread has read its predecessor's states
 #pragma unroll
         for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(e_out[k] - size);
+#ifdef MIC_STAMP
+        if (tid == 0) u.dbg[12] += 1;                                     // rounds
+#endif
         if (!__syncthreads_or(changed)) break;
     }
     __syncthreads();
