@@ -156,22 +156,23 @@ __device__ __forceinline__ uint32_t tk_wave_incl_max(uint32_t v, uint32_t) {
     v = max(v, TK_DPP(v, 0x142, 0xA)); v = max(v, TK_DPP(v, 0x143, 0xC));
     return v;
 }
-// 16 per-wave partials in LDS -> this wave's exclusive prefix and the group total (add / max)
+// TK_WAVES per-wave partials in LDS -> this wave's exclusive prefix and the group total (add / max).  Every lane
+// takes partial (lane & 7); a 3-step DPP scan inside the row and two lane reads replace a loop over the partials.
 __device__ __forceinline__ void tk_block16_add(const uint32_t *s, uint32_t wave, uint32_t &excl, uint32_t &total) {
-    const uint4 a = ((const uint4 *)s)[0], b = ((const uint4 *)s)[1], c = ((const uint4 *)s)[2], d = ((const uint4 *)s)[3];
-    const uint32_t v[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
-    uint32_t e = 0, t = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { e += ((uint32_t)w < wave) ? v[w] : 0u; t += v[w]; }
-    excl = e; total = t;
+    const uint32_t v = s[threadIdx.x & 7];
+    uint32_t x = v;
+    x += TK_DPP(x, 0x111, 0xF); x += TK_DPP(x, 0x112, 0xF); x += TK_DPP(x, 0x114, 0xF);     // inclusive over lanes 0..7 of each row
+    const uint32_t w = __builtin_amdgcn_readfirstlane(wave);
+    total = __builtin_amdgcn_readlane(x, 7);
+    excl = __builtin_amdgcn_readlane(x, w) - __builtin_amdgcn_readlane(v, w);
 }
 __device__ __forceinline__ void tk_block16_max(const uint32_t *s, uint32_t wave, uint32_t &excl, uint32_t &total) {
-    const uint4 a = ((const uint4 *)s)[0], b = ((const uint4 *)s)[1], c = ((const uint4 *)s)[2], d = ((const uint4 *)s)[3];
-    const uint32_t v[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
-    uint32_t e = 0, t = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { e = max(e, ((uint32_t)w < wave) ? v[w] : 0u); t = max(t, v[w]); }
-    excl = e; total = t;
+    const uint32_t v = s[threadIdx.x & 7];
+    uint32_t x = v;
+    x = max(x, TK_DPP(x, 0x111, 0xF)); x = max(x, TK_DPP(x, 0x112, 0xF)); x = max(x, TK_DPP(x, 0x114, 0xF));
+    const uint32_t w = __builtin_amdgcn_readfirstlane(wave);
+    total = __builtin_amdgcn_readlane(x, 7);
+    excl = w ? __builtin_amdgcn_readlane(x, w - 1) : 0u;
 }
 
 typedef uint32_t tk_v2 __attribute__((ext_vector_type(2)));
@@ -240,6 +241,8 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     __syncthreads();
     // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile)
     struct TkFetch { tk_v2 cv, tv; uint32_t lft, x, y; bool row4; };
+    const uint32_t tile_dy = TP / W, tile_dx = TP - tile_dy * W;   // a tile further on: tile_dy rows and tile_dx columns
+    uint32_t ny = (tid * TK_PPT) / W, nx = tid * TK_PPT - ny * W;  // position of this thread's first pixel in the next tile to fetch
     auto fetch = [&](uint32_t tile) -> TkFetch {
         TkFetch f; f.cv = tk_v2{0u, 0u}; f.tv = tk_v2{0u, 0u}; f.lft = 0; f.x = 0; f.y = 0; f.row4 = false;
         const uint32_t gb = tile * TP + tid * TK_PPT;
@@ -248,7 +251,9 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
             if (gb + TK_PPT <= npx) { f.cv = *(const TkD *)(in + gb); f.row4 = true; }
             return f;
         }
-        f.y = gb / W; f.x = gb - f.y * W;
+        f.x = nx; f.y = ny;                                     // tiles are fetched in order: the position advances by a tile
+        nx += tile_dx; ny += tile_dy;
+        if (nx >= W) { nx -= W; ny++; }
         f.row4 = f.x + TK_PPT <= W;                             // the 4 pixels share a row
         if (f.row4) {
             f.cv = *(const TkD *)(in + gb);
@@ -419,6 +424,9 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
                 }
             }
         }
+#ifdef MIC_STAMP
+        if (!__all(fast || !V) && lane == 0) atomicAdd(&u.dbg[15], 1u);   // wave-tiles that take the general path
+#endif
         const uint32_t tincl = tk_wave_incl_add(tsum, lane);
         if (lane == 63) s_tc[wave] = tincl;
         __syncthreads();
@@ -438,8 +446,12 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
 #pragma unroll
                 for (int q = 0; q < TK_SPT; q++) dmax = max(dmax, v[q + 3] - hlo);
                 if (dmax < TK_HWIN) {
+#ifdef TK_ABL_NOHIST
+                    atomicAdd(&s_hist[v[3] - hlo], 8u);
+#else
 #pragma unroll
                     for (int q = 0; q < TK_SPT; q++) atomicAdd(&s_hist[v[q + 3] - hlo], 1u);
+#endif
                 } else {
 #pragma unroll
                     for (int q = 0; q < TK_SPT; q++) count_tok(v[q + 3]);

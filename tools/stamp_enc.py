@@ -13,7 +13,7 @@ sess = mic.Session(len(units), W * 256); cu = mic.Session.make_units(units)
 sess.encode_enqueue(d_px.data_ptr(), cu); d_blobs, offs, st, ns = sess.encode_finish(); assert (st == 0).all()
 buf = (C.c_uint32 * 32)()
 names = ["tok.A symbols", "tok.B facts", "tok.C counts", "tok.D write", "tok.E carry", "tab.normalise", "tab.ncount", "tab.ctable",
-         "tans.walk", "tans.fixup", "tans.bits", "tans.pack", "fix.rounds", "fix.rewalkers", "fix.maxgroups"]
+         "tans.walk", "tans.fixup", "tans.bits", "tans.pack", "fix.rounds", "fix.rewalkers", "fix.maxgroups", "tok.slow_wavetiles"]
 for i in range(len(units)):
     mic.lib().mic_hip_debug_unit(sess._h, i, buf)
     print(f"unit {i}: ntok={buf[0]} " + " ".join(f"{n}={buf[16 + k]}" for k, n in enumerate(names)))
