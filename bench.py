@@ -77,8 +77,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "288")),
-                    help="frames per GPU per step (288 x 8 strips = 9 tANS decode streams on each of the 256 CUs)")
+    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "256")),
+                    help="frames per GPU per step (256 x 8 strips = 8 tANS decode streams, 4 two-stream waves, on each of the 256 CUs)")
     ap.add_argument("--strips", type=int, default=8)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--cols", type=int, default=2577)

@@ -325,14 +325,19 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
         q -= (int32_t)tl;
     }
     // one group = N symbols, states 0..N-1 in order; a pair takes <= 30 bits off one 32-bit window
-    auto group = [&](uint32_t *stage_w) {
+    // stage layout: stage16[k * G + g] = state k of group g (one 16-bit store per state: the LDS port has slack, the
+    // VALU does not, and stores 2 * G bytes apart cannot be re-packed into a v_perm + 32-bit store)
+    auto group = [&](uint16_t *stage_g) {
         uint32_t e[N];
 #pragma unroll
         for (int k = 0; k < N; k++) e[k] = chain_o[st[k]];
 #pragma unroll
         for (int p = 0; p < N; p += 2) {
             const uint32_t hi = window(q);
-            stage_w[p >> 1] = (TLHI == 16 ? (st[p] & 0xFFFFu) : st[p]) | (st[p + 1] << 16);   // tableLog 16: low half = state - size
+            // two 16-bit stores (the LDS port has slack, the VALU does not: no pack instruction); tableLog 16: the
+            // low half of a state is state - size
+            stage_g[p * (128 / N)] = (uint16_t)st[p];                   // tableLog 16: the low half of a state is state - size
+            stage_g[(p + 1) * (128 / N)] = (uint16_t)st[p + 1];
             // m = -nbBits (nextState >= 1, so clz is defined); a funnel shift right by m mod 32 = 32 - nbBits
             // both appends the bits to nextState and moves the window on to the second state
             const uint32_t m0 = C - (uint32_t)__builtin_clz(e[p]), m1 = C - (uint32_t)__builtin_clz(e[p + 1]);
@@ -346,6 +351,14 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
                 st[p + 1] = __builtin_amdgcn_alignbit(e[p + 1], hi1, m1);
             }
             q += (int32_t)m0 + (int32_t)m1;
+            if (N == 2 && !ZB) {
+                // issue order of a pair: the four address ops, the three LDS reads the chain waits for, then the two
+                // stage stores in the shadow of that wait, then the nine ops that turn the entries into the next states
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+            }
         }
     };
     // one symbol with state k (tail: fse2state.go:293-305 and siblings)
@@ -395,22 +408,32 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
     };
     constexpr uint32_t G = 128 / N;                                     // groups per 128-symbol chunk
     const uint32_t chunks = count / 128;
+#ifdef MIC_STAMP
+    const uint64_t ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t vzero;                                                     // a zero the compiler cannot see through: keeps the stage
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                      // address in a VGPR (else: one v_mov from an SGPR per store)
+    uint16_t *const stage_v = (uint16_t *)stage + vzero;
     uint32_t pend_lo = 0, pend_hi = 0; bool have_pend = false;          // symbols gathered for the previous chunk (joined only
                                                                         // at the store: joining earlier would wait for the gather)
     uint32_t obase = 0;                                                 // dword index of the pending chunk in out
     for (uint32_t ch = 0; ch < chunks; ch++) {
+        // eight groups per loop body, their stage slots at immediate offsets from one VGPR base
+        auto groups = [&](uint32_t g0, uint32_t g1) {
+            for (uint32_t gi = g0; gi < g1; gi += 8) {
+                uint16_t *const sg = stage_v + gi;
+#pragma unroll
+                for (int j = 0; j < 8; j++) group(sg + j);
+            }
+        };
+        static_assert(G % 16 == 0, "chunk halves are whole loop bodies");
         if (TLHI == 16) {                                               // 16 bits a symbol: refresh the ring mid-chunk as well
-#pragma unroll 8
-            for (uint32_t gi = 0; gi < G / 2; gi++) group(stage + gi * (N / 2));
+            groups(0, G / 2);
             store_blk(blk - 2, pf);
             blk = (q >> 5) >> 6;
             pf = load_blk(blk - 2);
-#pragma unroll 8
-            for (uint32_t gi = G / 2; gi < G; gi++) group(stage + gi * (N / 2));
-        } else {
-#pragma unroll 8
-            for (uint32_t gi = 0; gi < G; gi++) group(stage + gi * (N / 2));
-        }
+            groups(G / 2, G);
+        } else groups(0, G);
         // this chunk's 128 states are staged: write out the previous chunk, gather this one
         store_blk(blk - 2, pf);
         if (have_pend) {
@@ -425,8 +448,10 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
         }
         blk = (q >> 5) >> 6;
         pf = load_blk(blk - 2);
-        const uint32_t s2 = stage[lane];
-        pend_lo = symg[s2 & 0xFFFF]; pend_hi = symg[s2 >> 16];
+        {   // lane l translates tokens 2l and 2l+1 = states (2l % N), (2l % N) + 1 of group 2l / N
+            const uint16_t *sg = (const uint16_t *)stage + ((2 * lane) % N) * G + (2 * lane) / N;
+            pend_lo = symg[sg[0]]; pend_hi = symg[sg[G]];
+        }
         have_pend = true; obase = ch * 64;
     }
     if (have_pend) {
@@ -444,25 +469,309 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
         const uint32_t done = chunks * 128;
         const uint32_t rem = count - done;
         uint32_t k = 0;
-        for (; k + N <= rem; k += N) group(stage + (k / 2));
         uint16_t *st16 = (uint16_t *)stage;
+        for (; k + N <= rem; k += N) group(st16 + k / N);
 #pragma unroll
-        for (int j = 0; j < N - 1; j++) if (k + (uint32_t)j < rem) single(j, st16 + k + j);
+        for (int j = 0; j < N - 1; j++) if (k + (uint32_t)j < rem) single(j, st16 + j * G + k / N);
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        auto staged = [&](uint32_t t) -> uint32_t { return st16[(t % N) * G + t / N]; };   // token t of the tail
         uint32_t tv0 = 0, tv1 = 0;
-        if (lane < rem) { tv0 = symg[st16[lane]]; out[done + lane] = (uint16_t)tv0; }
-        if (lane + 64 < rem) { tv1 = symg[st16[lane + 64]]; out[done + lane + 64] = (uint16_t)tv1; }
+        if (lane < rem) { tv0 = symg[staged(lane)]; out[done + lane] = (uint16_t)tv0; }
+        if (lane + 64 < rem) { tv1 = symg[staged(lane + 64)]; out[done + lane + 64] = (uint16_t)tv1; }
         walk(count, [&](uint32_t pos) -> uint32_t {
             const uint32_t rel = pos - done;
             return (rel < 64) ? __builtin_amdgcn_readlane(tv0, rel) : __builtin_amdgcn_readlane(tv1, rel - 64);
         });
     }
+#ifdef MIC_STAMP
+    if (lane == 0) { u.dbg[8] = (uint32_t)(__builtin_amdgcn_s_memtime() - ck0); u.dbg[9] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0); }
+#endif
     if (lane == 0) {
         // bits still unread = grid bits [8*sb, q+32)
         if (q + 32 - (int32_t)(8u * sb) < 0) u.status = MICD_ERR_CORRUPT;   // bitreader.go:113-120
         else {
             u.ntok = count;
             if (u.mode == 0 && u.seg != nullptr && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_symcap); u.walk_ok = 1; }
+        }
+    }
+}
+
+// ==========================================================================================
+// Two streams per wave (tableLog <= 13).  A SIMD issues one instruction per 4-cycle turn whatever its kind
+// (measured: a stream runs at 134 cycles per symbol pair alone, 142 with one wave per SIMD, ~214 with two, and a
+// launch waits for its slowest wave), so with more than one wave per SIMD the decode is bound by instructions
+// issued per pair -- about 21 -- and every lane of those instructions computes the same thing.  Here lanes 0-31 run
+// stream 2w and lanes 32-63 stream 2w+1 through the SAME instructions: per-half values (table base, ring base, bit
+// position, states, tableLog) live in VGPRs, the two tables / rings / stages sit side by side in LDS (35.5 KiB per
+// wave: four waves = eight streams per CU, one wave per SIMD), and a pair of streams costs what one did.
+// The halves differ in length: the loop runs for the longer one; the shorter one keeps decoding harmless garbage
+// (every table entry is valid, the ring wraps, block loads are bounds-checked) behind a snapshot of its true end
+// state, and its stores and header walk are switched off.  Units of another class in a pair are left to the
+// single-stream kernels.  LDS bytes: ring A 0, stage A 1056, ring B 2048, stage B 3104, table A 3584, table B 19968.
+#define T2_TAB0 3584u
+#define T2_LDS (T2_TAB0 + 2u * 16384u)
+template <int N, bool ZB>
+__global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units) {
+    extern __shared__ uint32_t s_mem[];
+    typedef __attribute__((address_space(3))) uint32_t *l32;
+    typedef __attribute__((address_space(3))) uint16_t *l16;
+    typedef const __attribute__((address_space(1))) uint16_t *gcu16;
+    typedef const __attribute__((address_space(1))) uint32_t *gcu32;
+    typedef __attribute__((address_space(1))) uint16_t *gu16;
+    typedef uint32_t g_v2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout below assumes dynamic LDS at 0
+    const int ui = (int)blockIdx.x * 2 + (int)half;
+    bool mine = ui < n_units;
+    MicUnit &u = units[mine ? ui : 0];
+    uint32_t tl = 13, count = 0, len = 4, bits_off = 0;
+    if (mine) {
+        const uint32_t flav = u.flavour;
+        tl = u.table_log; count = u.count; bits_off = u.bits_off;
+        mine = u.status == MICD_OK && flav != 1 && ((flav == 108) ? 8u : flav) == (uint32_t)N && tl >= 5 && tl <= 13 &&
+               ((u.zero_bits != 0) == ZB) && u.ntok == 0;
+        if (mine && bits_off >= u.comp_len) { if (hl == 0) u.status = MICD_ERR_CORRUPT; mine = false; }
+        if (mine) { len = u.comp_len - bits_off; if (len >= (1u << 27)) mine = false; }   // 32-bit bit positions here; serial kernel takes it
+        if (!mine) { tl = 13; count = 0; len = 4; }
+    }
+    if (!__any(mine)) return;
+    const uint32_t size = 1u << tl;
+    const uint32_t ringb = half << 11, stageb = 1056u + (half << 11), tabb = T2_TAB0 + (half << 14);
+    // ---- tables: u16 nextState = (newState + size) >> nbBits, 32 lanes per stream ----
+    if (mine) {
+        const uint32_t *dt = u.tt_nb;
+        for (uint32_t p = hl * 2; p < size; p += 64) {
+            const uint2 e = *(const uint2 *)(dt + p);
+            const uint32_t n0 = ((e.x & 0xFFFF) + size) >> (e.x >> 16), n1 = ((e.y & 0xFFFF) + size) >> (e.y >> 16);
+            *(l32)(uintptr_t)(tabb + p * 2) = n0 | (n1 << 16);
+        }
+    }
+    const gcu16 symg = (gcu16)(u.tab_sym - size);
+    const gu16 out = (gu16)u.tok;
+    const uint8_t *bs = u.comp_in + bits_off;
+    uint32_t last = mine ? (uint32_t)bs[len - 1] : 1u;
+    if (mine && last == 0) { if (hl == 0) u.status = MICD_ERR_CORRUPT; mine = false; count = 0; last = 1; }   // bitreader.go:36-38
+    const uintptr_t addr = (uintptr_t)bs;
+    const uint32_t sb = (uint32_t)(addr & 3);
+    const gcu32 g = (gcu32)(addr - sb);
+    const int32_t cur0 = (int32_t)(8u * (len - 1) + (uint32_t)(31 - __clz(last)) + 8u * sb);
+    const int32_t top_dw = mine ? (cur0 - 1) >> 5 : -1;
+    // block b of a stream = its grid dwords [64b, 64b+64): two per lane
+    auto load_blk = [&](int32_t b, uint32_t &v0, uint32_t &v1) {
+        const int32_t i0 = b * 64 + (int32_t)hl, i1 = i0 + 32;
+        v0 = (b >= 0 && i0 <= top_dw) ? __builtin_nontemporal_load(g + i0) : 0u;
+        v1 = (b >= 0 && i1 <= top_dw) ? __builtin_nontemporal_load(g + i1) : 0u;
+    };
+    auto store_blk = [&](int32_t b, uint32_t v0, uint32_t v1) {
+        const uint32_t slot = ((uint32_t)b & 3u) * 64u + hl;
+        *(l32)(uintptr_t)(ringb + slot * 4) = v0;
+        *(l32)(uintptr_t)(ringb + (slot + 32) * 4) = v1;
+        if (slot == 0) *(l32)(uintptr_t)(ringb + 1024) = v0;              // mirror: a 2-dword read at slot 255 stays linear
+    };
+    int32_t q = cur0 - 32;
+    int32_t blk = (q >> 5) >> 6;
+    { uint32_t a0, a1; load_blk(blk + 1, a0, a1); store_blk(blk + 1, a0, a1); load_blk(blk, a0, a1); store_blk(blk, a0, a1);
+      load_blk(blk - 1, a0, a1); store_blk(blk - 1, a0, a1); }
+    uint32_t pf0, pf1; load_blk(blk - 2, pf0, pf1);
+    __syncthreads();
+    auto window = [&](int32_t qq) -> uint32_t {
+        const uint32_t a = (((uint32_t)qq >> 3) & 0x3FCu) | ringb;
+        const uint32_t w0 = *(l32)(uintptr_t)a, w1 = *(l32)(uintptr_t)(a + 4);
+        return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)qq);
+    };
+    const uint32_t C = 31u - tl;
+    const uint32_t cb = tabb - 2u * size;                                   // byte address of entry s = 2*s + cb, s in [size, 2*size)
+    auto entry = [&](uint32_t st) -> uint32_t { return *(l16)(uintptr_t)(st * 2 + cb); };
+    uint32_t st[N];
+#pragma unroll
+    for (int p = 0; p < N; p++) { st[p] = size + (window(q) >> (32u - tl)); q -= (int32_t)tl; }
+    constexpr uint32_t G = 128 / N;
+    // stage16[k * G + g] = state k of group g
+    auto group = [&](l16 sg) {                                              // sg -> stage slot (0, g); pointer, so that the
+        uint32_t e[N];                                                      // slots of a loop body become immediate offsets
+#pragma unroll
+        for (int k = 0; k < N; k++) e[k] = entry(st[k]);
+#pragma unroll
+        for (int p = 0; p < N; p += 2) {
+            const uint32_t hi = window(q);
+            sg[p * G] = (uint16_t)st[p];
+            sg[(p + 1) * G] = (uint16_t)st[p + 1];
+            const uint32_t m0 = C - (uint32_t)__builtin_clz(e[p]), m1 = C - (uint32_t)__builtin_clz(e[p + 1]);
+            if (ZB) {
+                const uint32_t hi1 = hi << (0u - m0);
+                st[p] = (uint32_t)((((uint64_t)e[p] << 32) | hi) >> (32u + m0));
+                st[p + 1] = (uint32_t)((((uint64_t)e[p + 1] << 32) | hi1) >> (32u + m1));
+            } else {
+                const uint32_t hi1 = __builtin_amdgcn_alignbit(hi, 0u, m0);
+                st[p] = __builtin_amdgcn_alignbit(e[p], hi, m0);
+                st[p + 1] = __builtin_amdgcn_alignbit(e[p + 1], hi1, m1);
+            }
+            q += (int32_t)m0 + (int32_t)m1;
+            if (N == 2 && !ZB) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+            }
+        }
+    };
+    const uint32_t chunks = count / 128, rem = count - chunks * 128;
+    const uint32_t maxch = max((uint32_t)__builtin_amdgcn_readlane(chunks, 0), (uint32_t)__builtin_amdgcn_readlane(chunks, 32));
+    // per-half header walkers (uniform values, one set per half)
+    bool w_on[2], w_err[2]; uint32_t w_pos[2], w_out[2], w_nseg[2], w_mid[2], w_symcap[2], w_segcap[2], w_cnt[2];
+    __attribute__((address_space(1))) g_v2 *w_seg[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int ln = h * 32;
+        const uint32_t on = (mine && u.mode == 0 && u.seg != nullptr) ? 1u : 0u;
+        w_on[h] = __builtin_amdgcn_readlane(on, ln) != 0; w_err[h] = false;
+        w_pos[h] = 0; w_out[h] = 0; w_nseg[h] = 0; w_mid[h] = 0;
+        const uint32_t sc = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);
+        w_symcap[h] = __builtin_amdgcn_readlane(sc, ln); w_segcap[h] = __builtin_amdgcn_readlane(u.seg_cap, ln);
+        w_cnt[h] = __builtin_amdgcn_readlane(count, ln);
+        const uint64_t sp = (uint64_t)(uintptr_t)u.seg;
+        const uint64_t spu = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(sp >> 32), ln) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)sp, ln);
+        w_seg[h] = (__attribute__((address_space(1))) g_v2 *)(uintptr_t)spu;
+    }
+    auto walk = [&](int h, uint32_t cend, auto get) {                       // as in k_dec_tans_lds
+        while (w_on[h] && w_pos[h] < cend) {
+            const uint32_t hd = get(w_pos[h]);
+            if (w_pos[h] == 0) {
+                const int d0 = mic_len16((uint16_t)hd);
+                if (d0 == 0) { w_on[h] = false; w_err[h] = true; break; }
+                w_mid[h] = (1u << (d0 - 1)) - 1; w_pos[h] = 1;
+                continue;
+            }
+            if (w_out[h] >= w_symcap[h]) { w_on[h] = false; break; }
+            if (hd == 0 || w_nseg[h] >= w_segcap[h]) { w_on[h] = false; w_err[h] = true; break; }
+            if (hd <= w_mid[h]) {
+                if (w_pos[h] + 1 >= w_cnt[h]) { w_on[h] = false; w_err[h] = true; break; }
+                if (lane == 0) { g_v2 r; r.x = (w_pos[h] + 1) | 0x80000000u; r.y = w_out[h]; w_seg[h][w_nseg[h]] = r; }
+                w_nseg[h]++; w_out[h] += hd; w_pos[h] += 2;
+            } else {
+                if (lane == 0) { g_v2 r; r.x = w_pos[h] + 1; r.y = w_out[h]; w_seg[h][w_nseg[h]] = r; }
+                w_nseg[h]++; w_out[h] += hd - w_mid[h]; w_pos[h] += 1 + (hd - w_mid[h]);
+            }
+        }
+    };
+    // lane j of a half translates tokens 4j .. 4j+3 of a chunk: pend0 = tokens 4j, 4j+1; pend1 = 4j+2, 4j+3
+    uint32_t pend[4] = { 0u, 0u, 0u, 0u }; bool have_pend = false; uint32_t pch = 0;
+    auto flush_pend = [&]() {
+        if (!have_pend) return;
+        const uint32_t p0 = pend[0] | (pend[1] << 16), p1 = pend[2] | (pend[3] << 16);
+        if (mine && pch < chunks) { g_v2 v; v.x = p0; v.y = p1; __builtin_nontemporal_store(v, (__attribute__((address_space(1))) g_v2 *)(out + pch * 128) + hl); }
+        const uint32_t cbase = pch * 128;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (pch < (uint32_t)__builtin_amdgcn_readlane(chunks, h * 32))
+                walk(h, cbase + 128, [&](uint32_t pos) -> uint32_t {
+                    const uint32_t rel = pos - cbase;
+                    const uint32_t d = (rel & 2) ? __builtin_amdgcn_readlane(p1, h * 32 + (rel >> 2)) : __builtin_amdgcn_readlane(p0, h * 32 + (rel >> 2));
+                    return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
+                });
+        }
+    };
+    // the shorter half's true end-of-chunks state
+    uint32_t sv_st[N]; int32_t sv_q = q;
+#pragma unroll
+    for (int k = 0; k < N; k++) sv_st[k] = st[k];
+    for (uint32_t ch = 0; ch < maxch; ch++) {
+        if (ch == chunks) {                                                  // (per lane) this half is done: keep its state aside
+            sv_q = q;
+#pragma unroll
+            for (int k = 0; k < N; k++) sv_st[k] = st[k];
+        }
+        for (uint32_t gi = 0; gi < G; gi += 8) {
+            const l16 sg = (l16)(uintptr_t)(stageb + gi * 2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) group(sg + j);
+        }
+        store_blk(blk - 2, pf0, pf1);
+        flush_pend();
+        blk = (q >> 5) >> 6;
+        load_blk(blk - 2, pf0, pf1);
+        {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t tok = 4 * hl + t;
+                const uint32_t sv = *(l16)(uintptr_t)(stageb + ((tok % N) * G + tok / N) * 2);
+                pend[t] = mine ? (uint32_t)symg[sv] : 0u;                   // (a foreign half decodes garbage: keep it off the symbol table)
+            }
+        }
+        have_pend = true; pch = ch;
+    }
+    flush_pend();
+    if (chunks < maxch) {                                                    // (per lane) restore the true state of the shorter half
+        q = sv_q;
+#pragma unroll
+        for (int k = 0; k < N; k++) st[k] = sv_st[k];
+    }
+    if (maxch) {   // ... and put its ring back where that state reads (the run-off moved it on); harmless for the other half
+        blk = (q >> 5) >> 6;
+        uint32_t a0, a1;
+        load_blk(blk + 1, a0, a1); store_blk(blk + 1, a0, a1);
+        load_blk(blk, a0, a1); store_blk(blk, a0, a1);
+        load_blk(blk - 1, a0, a1); store_blk(blk - 1, a0, a1);
+        __syncthreads();
+    }
+    // ---- tails: rem < 128 tokens per half, predicated per lane ----
+    {
+        const uint32_t done = chunks * 128;
+        for (uint32_t k = 0; k < 128; k += N) {
+            if (!__any(k < rem)) break;
+            const bool whole = k + N <= rem;
+            uint32_t st_b[N]; const int32_t q_b = q;
+#pragma unroll
+            for (int i = 0; i < N; i++) st_b[i] = st[i];
+            if (__any(whole)) group((l16)(uintptr_t)(stageb + (k / N) * 2));   // all N states of group k / N
+            if (!whole) {                                                    // this half: the last partial group, state by state, or nothing
+                q = q_b;
+#pragma unroll
+                for (int i = 0; i < N; i++) st[i] = st_b[i];
+#pragma unroll
+                for (int i = 0; i < N - 1; i++) {
+                    if (k + (uint32_t)i < rem) {
+                        const uint32_t e = entry(st[i]);
+                        const uint32_t hi = window(q);
+                        *(l16)(uintptr_t)(stageb + (i * G + k / N) * 2) = (uint16_t)st[i];
+                        const uint32_t nb = (uint32_t)__builtin_clz(e) - C;
+                        st[i] = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
+                        q -= (int32_t)nb;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        uint32_t tv[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t tok = 4 * hl + t;
+            if (mine && tok < rem) {
+                tv[t] = symg[*(l16)(uintptr_t)(stageb + ((tok % N) * G + tok / N) * 2)];
+                out[done + tok] = (uint16_t)tv[t];
+            }
+        }
+        const uint32_t p0 = tv[0] | (tv[1] << 16), p1 = tv[2] | (tv[3] << 16);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane(done, h * 32);
+            walk(h, w_cnt[h], [&](uint32_t pos) -> uint32_t {
+                const uint32_t rel = pos - dn;
+                const uint32_t d = (rel & 2) ? __builtin_amdgcn_readlane(p1, h * 32 + (rel >> 2)) : __builtin_amdgcn_readlane(p0, h * 32 + (rel >> 2));
+                return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
+            });
+        }
+    }
+    if (hl == 0 && mine) {
+        if (q + 32 - (int32_t)(8u * sb) < 0) u.status = MICD_ERR_CORRUPT;   // bitreader.go:113-120
+        else {
+            u.ntok = count;
+            const bool werr = half ? w_err[1] : w_err[0];
+            if (u.mode == 0 && u.seg != nullptr && !werr) {
+                u.nseg = half ? w_nseg[1] : w_nseg[0];
+                u.nsym = min(half ? w_out[1] : w_out[0], half ? w_symcap[1] : w_symcap[0]);
+                u.walk_ok = 1;
+            }
         }
     }
 }
@@ -659,6 +968,25 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         mic_launch_dec_tables(d_units, n, stream);
     }
     if (variant != 100) {
+        static bool duo_attr = false;
+        if (!duo_attr) {
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            duo_attr = true;
+        }
+        const unsigned nw = (unsigned)((n + 1) / 2);
+        if (t) t->mark("k_dec_tans_duo<2,false>");
+        hipLaunchKernelGGL((k_dec_tans_duo<2, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        if (t) t->mark("k_dec_tans_duo<other>");
+        hipLaunchKernelGGL((k_dec_tans_duo<2, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<4, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<4, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<8, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<8, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
         launch_tans_lds<2, false>(d_units, n, stream, t, "k_dec_tans_lds<2,false,13>");
         launch_tans_lds<4, false>(d_units, n, stream, t, "k_dec_tans_lds<4,false,13>");
         launch_tans_lds<8, false>(d_units, n, stream, t, "k_dec_tans_lds<8,false,13>");

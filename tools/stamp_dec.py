@@ -8,7 +8,7 @@ import torch
 mic = entry.load_package(); synth = importlib.import_module("medical_image_codec_amd.synth")
 W, H = 2577, 2048
 img = synth.xr_like(cols=W, rows=H, depth=12, seed=1)
-for F in (1, int(os.environ.get("FRAMES", "288"))):
+for F in (1, 128, int(os.environ.get("FRAMES", "288"))):
     host = np.stack([img] * F)
     d_px = torch.from_numpy(host.view(np.int16)).cuda(); d_out = torch.empty_like(d_px)
     units = [(f * W * H + y0 * W, W, 256, 4095, 2) for f in range(F) for y0 in range(0, H, 256)]
@@ -18,5 +18,6 @@ for F in (1, int(os.environ.get("FRAMES", "288"))):
     buf = (C.c_uint32 * 32)()
     for i in (0, len(units) // 2, len(units) - 1):
         mic.lib().mic_hip_debug_unit(sess._h, i, buf)
-        print(f"F={F} unit {i}: nseg={buf[12]} nsym={buf[13]} px.fetch={buf[16]} px.scan={buf[17]} px.number={buf[18]} px.store={buf[19]}")
+        clk = buf[24] / max(buf[25], 1) * 100.0
+        print(f"F={F} unit {i}: px.fetch={buf[16]} px.scan={buf[17]} px.number={buf[18]} px.store={buf[19]}  tans: memtime={buf[24]} realtime={buf[25]} -> {clk:.0f} MHz, {buf[24] / (buf[0] / 2):.1f} ticks/pair")
     sess.close(); del d_px, d_out
