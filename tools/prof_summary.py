@@ -26,7 +26,14 @@ def pmc(db, counter):
 
 
 def short(name):
-    return name.replace("void ", "").replace("(MicUnit*)", "").replace("(MicUnit*, int, int)", "")
+    name = name.replace("void ", "")
+    depth = 0
+    for i in range(len(name) - 1, -1, -1):            # drop the trailing argument list
+        if name[i] == ")": depth += 1
+        elif name[i] == "(":
+            depth -= 1
+            if depth == 0: return name[:i]
+    return name
 
 
 def main():
