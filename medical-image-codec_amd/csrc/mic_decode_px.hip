@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
             // it; reload rounds overlap by 8 segments (a window of 8 symbols spans at most 8).
             const uint32_t i0 = base + tid * PX_SPT;
             const uint32_t wend = min(i0 + PX_SPT, tile_end);            // this thread's symbols are [i0, wend)
+            const uint32_t par = (base / PX_T) & 1u;                     // s_misc[5 + par]: first segment of the next tile
             uint32_t w8[4] = { 0u, 0u, 0u, 0u };
             bool got = i0 >= tile_end;
             uint32_t my_seg = s_lo;                                      // segment this thread found (absolute index; hint for the next tile)
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
 #pragma unroll
                     for (int k = 0; k < 4; k++) w8[k] = p8[k];
                     if (pre_bad) s_misc[3] = 1;
-                    if (wend == tile_end) s_misc[5] = tab_r0 + pre_j;
+                    if (wend == tile_end) s_misc[5 + par] = tab_r0 + pre_j;
                     my_seg = tab_r0 + pre_j; got = true;
                 }
             } else {
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
                         uint32_t bad = 0, j;
                         fetch8(i0, wend, (s_lo > r0) ? s_lo - r0 : 0u, w8, bad, j);
                         if (bad) s_misc[3] = 1;
-                        if (wend == tile_end) s_misc[5] = r0 + j;        // segment of the tile's last symbol: where the next tile starts
+                        if (wend == tile_end) s_misc[5 + par] = r0 + j;  // segment of the tile's last symbol: where the next tile starts
                         my_seg = r0 + j; got = true;
                     }
                     if (!(cover_end < tile_end)) break;
@@ -214,6 +215,29 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
                 const bool in = i < tile_end && i != 0;                  // symbol 0 is the max value, not a pixel
                 if (in) vmask |= 1u << k;
                 if (in && x == delim) dmask |= 1u << k;
+            }
+            // Tiles without a delimiter (almost all: escapes are rare) need no scan: every symbol is a pixel and goes
+            // straight from the registers to its place.  The barrier publishes the fetch phase's verdicts either way.
+            const bool plain = !__syncthreads_or((int)(dmask != 0)) && carry_state == 0;
+            s_lo = s_misc[5 + par];
+            if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+            if (plain) {
+                const uint32_t z = (base == 0) ? 1u : 0u;                // symbol 0 is not a pixel
+                const uint32_t cnt_all = tile_end - base - z;
+                const uint32_t n_out = min(cnt_all, npx - carry_px);
+                const uint32_t l0 = tid * PX_SPT - z;                    // tile-local pixel index of symbol i0 (tid 0, z = 1: of symbol 1)
+                if (vmask == 0xFFu && l0 + PX_SPT <= n_out) {
+                    px_v4 v; v.x = w8[0]; v.y = w8[1]; v.z = w8[2]; v.w = w8[3];
+                    *(PxQ *)(px + carry_px + l0) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PX_SPT; k++) {
+                        const uint32_t l = tid * PX_SPT + k - z;
+                        if (((vmask >> k) & 1u) && l < n_out) px[carry_px + l] = (uint16_t)((w8[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                    }
+                }
+                carry_px += cnt_all;
+                continue;
             }
             uint32_t tr;
             {
@@ -246,8 +270,6 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
             if (lane == 0) excl = 2u;                                    // identity: s0 = 0, s1 = 1, no pixels
             __syncthreads();
             MIC_STAMP_AT(u, 1);
-            s_lo = s_misc[5];                                            // (this barrier also publishes the fetch phase's verdicts)
-            if (s_misc[3]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
             // entry (state, pixel count) of this wave and exit of the tile, from the 16 wave totals
             uint32_t st_w = carry_state, cnt_w = 0, st_all, cnt_all;
             {
