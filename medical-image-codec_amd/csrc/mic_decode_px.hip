@@ -23,7 +23,8 @@
 #define PX_T 8192                                 // symbols per tile of the expansion / numbering pass
 #define PX_SPT (PX_T / PX_THREADS)                // symbols per thread
 #define PX_K 8                                    // pixels per thread per wavefront step (in-work-group fallback)
-#define PR_K 32                                   // pixels per lane per step in k_dec_predict
+#define PR_K 64                                   // pixels per lane per step in k_dec_predict: one 128-byte line per row and step
+#define PR_DW (PR_K / 2)
 #define PR_MAX_W 32768                            // its row buffer is 2 bytes per column of LDS
 struct __attribute__((packed, aligned(2))) PxVec { uint16_t v[PX_K]; };
 
@@ -411,10 +412,10 @@ typedef pr_v2 PrD __attribute__((aligned(2)));
 typedef uint32_t PrS __attribute__((aligned(2)));
 typedef __attribute__((address_space(1))) uint16_t *pr_gu16;
 
-// cnt (1..32, wave-uniform) pixels of a group, packed two per dword
-__device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[16], int cnt) {
+// cnt (1..PR_K, wave-uniform) pixels of a group, packed two per dword
+__device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[PR_DW], int cnt) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < PR_K / 8; q++) {
         const int j = 4 * q;
         pr_gu16 o = dst + 8 * q;
         if (cnt >= 8 * q + 8) {
@@ -438,8 +439,8 @@ __device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[16
 }
 
 struct PrSlot {
-    uint32_t d[16];       // 32 symbols
-    uint32_t w0, w1;      // flag words around the group (funnel-shifted at use: consuming them at fetch time would
+    uint32_t d[PR_DW];    // PR_K symbols
+    uint32_t w0, w1, w2;  // flag words around the group (funnel-shifted at use: consuming them at fetch time would
                           // make the fetch wait for its own loads)
     int32_t g, y;         // group and row; g < 0 or act == 0: nothing to do
     uint32_t p;           // pixel index of the group's first pixel
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
     if (u.status != MICD_OK || u.mode != 0) return;
     const int W = u.w, H = u.h;
     if (W <= w_lo || W > w_hi) return;
-    extern __shared__ uint32_t s_rowbuf[];                       // ngrp x 16 dwords
+    extern __shared__ uint32_t s_rowbuf[];                       // ngrp x PR_DW dwords
     const uint32_t lane = threadIdx.x;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
     const uint32_t thr = u.dec_thr;
@@ -500,14 +501,14 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
         s.g = cg; s.y = y;
         s.act = (cg >= 0 && cg < ngrp && cb < nb && y < H) ? 1u : 0u;
         s.p = (uint32_t)y * (uint32_t)W + (uint32_t)cg * PR_K;
-        s.w0 = 0; s.w1 = 0;
+        s.w0 = 0; s.w1 = 0; s.w2 = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) s.d[i] = 0;
+        for (int i = 0; i < PR_DW; i++) s.d[i] = 0;
         if (s.act) {
             const pr_gu16 src = px + s.p;
             if (s.p + PR_K <= npx) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < PR_K / 8; q++) {
                     const pr_v4 v = *(const __attribute__((address_space(1))) PrQ *)(src + 8 * q);
                     s.d[4 * q] = v.x; s.d[4 * q + 1] = v.y; s.d[4 * q + 2] = v.z; s.d[4 * q + 3] = v.w;
                 }
@@ -515,42 +516,43 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
                 for (int k = 0; k < PR_K; k++) if (s.p + (uint32_t)k < npx) {
                     const uint32_t v = src[k];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) if (i == (k >> 1)) s.d[i] |= v << (16 * (k & 1));
+                    for (int i = 0; i < PR_DW; i++) if (i == (k >> 1)) s.d[i] |= v << (16 * (k & 1));
                 }
             }
-            s.w0 = flags[s.p >> 5]; s.w1 = flags[(s.p >> 5) + 1];
+            s.w0 = flags[s.p >> 5]; s.w1 = flags[(s.p >> 5) + 1]; s.w2 = flags[(s.p >> 5) + 2];
         }
         if (++cg == P) { cg = 0; cb++; }
     };
-    uint32_t last[16];                                           // this lane's previous result = next lane's top
+    uint32_t last[PR_DW];                                        // this lane's previous result = next lane's top
 #pragma unroll
-    for (int i = 0; i < 16; i++) last[i] = 0;
+    for (int i = 0; i < PR_DW; i++) last[i] = 0;
     uint32_t left = 0;
     auto step = [&](const PrSlot &s) {
         // top neighbours: lane r-1's previous result; lane 0 takes the row buffer entry of its group
-        uint32_t top[16];
+        uint32_t top[PR_DW];
         {
             const int32_t gc = min(max(s.g, 0), ngrp - 1);
-            const uint4 *rb4 = (const uint4 *)(s_rowbuf + gc * 16);
-            uint32_t lv[16];
+            const uint4 *rb4 = (const uint4 *)(s_rowbuf + gc * PR_DW);
+            uint32_t lv[PR_DW];
 #pragma unroll
-            for (int i = 0; i < 16; i++) lv[i] = 0;
+            for (int i = 0; i < PR_DW; i++) lv[i] = 0;
             if (lane == 0) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const uint4 v = rb4[q]; lv[4 * q] = v.x; lv[4 * q + 1] = v.y; lv[4 * q + 2] = v.z; lv[4 * q + 3] = v.w; }
+                for (int q = 0; q < PR_DW / 4; q++) { const uint4 v = rb4[q]; lv[4 * q] = v.x; lv[4 * q + 1] = v.y; lv[4 * q + 2] = v.z; lv[4 * q + 3] = v.w; }
             }
 #pragma unroll
-            for (int i = 0; i < 16; i++) top[i] = __builtin_amdgcn_update_dpp(lv[i], last[i], 0x138, 0xF, 0xF, false);   // wave_shr:1
+            for (int i = 0; i < PR_DW; i++) top[i] = __builtin_amdgcn_update_dpp(lv[i], last[i], 0x138, 0xF, 0xF, false);   // wave_shr:1
         }
-        uint32_t res[16];
+        uint32_t res[PR_DW];
         if (s.g == 0) left = top[0] & 0xFFFFu;                   // column 0: predictor = top ((top+top)>>1)
-        uint32_t raw = __builtin_amdgcn_alignbit(s.w1, s.w0, s.p);   // bit k: pixel p + k is stored raw
-        if (s.y == 0) raw = 0xFFFFFFFFu;                         // row 0 comes ready-made from the row buffer
-        if (!s.act) raw = 0;
-        const bool any_raw = __any(raw != 0);
+        uint32_t raw_lo = __builtin_amdgcn_alignbit(s.w1, s.w0, s.p);   // bit k: pixel p + k is stored raw
+        uint32_t raw_hi = __builtin_amdgcn_alignbit(s.w2, s.w1, s.p);   // pixels p + 32 ..
+        if (s.y == 0) { raw_lo = 0xFFFFFFFFu; raw_hi = 0xFFFFFFFFu; }   // row 0 comes ready-made from the row buffer
+        if (!s.act) { raw_lo = 0; raw_hi = 0; }
+        const bool any_raw = __any((raw_lo | raw_hi) != 0);
         if (!any_raw) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
+            for (int i = 0; i < PR_DW; i++) {
                 const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
                 const uint32_t c0 = (s.d[i] & 0xFFFFu) - thr, c1 = (s.d[i] >> 16) - thr;
                 const uint32_t r0 = (((left + t0) >> 1) + c0) & 0xFFFFu;
@@ -561,12 +563,13 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
         } else {
             const bool row0 = s.y == 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
+            for (int i = 0; i < PR_DW; i++) {
+                const uint32_t raw = (i < 16) ? raw_lo >> (2 * (i & 15)) : raw_hi >> (2 * (i & 15));   // bits 0, 1: this dword's pixels
                 const uint32_t src = row0 ? top[i] : s.d[i];
                 const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
                 const uint32_t v0 = src & 0xFFFFu, v1 = src >> 16;
-                const uint32_t r0 = ((raw >> (2 * i)) & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
-                const uint32_t r1 = ((raw >> (2 * i + 1)) & 1u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
+                const uint32_t r0 = (raw & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
+                const uint32_t r1 = (raw & 2u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
                 res[i] = r0 | (r1 << 16);
                 left = r1;
             }
@@ -576,13 +579,13 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
             if (s.g < ngrp - 1 || tail == PR_K) pr_store_cnt(dst, res, PR_K);
             else pr_store_cnt(dst, res, tail);
             if (lane == 63) {
-                uint4 *rb4 = (uint4 *)(s_rowbuf + s.g * 16);
+                uint4 *rb4 = (uint4 *)(s_rowbuf + s.g * PR_DW);
 #pragma unroll
-                for (int q = 0; q < 4; q++) rb4[q] = make_uint4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+                for (int q = 0; q < PR_DW / 4; q++) rb4[q] = make_uint4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) last[i] = res[i];
+        for (int i = 0; i < PR_DW; i++) last[i] = res[i];
     };
     PrSlot sa, sb, sc;
     fetch(sa); fetch(sb); fetch(sc);

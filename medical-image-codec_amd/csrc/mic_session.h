@@ -75,7 +75,7 @@ struct mic_hip_session {
         blob_stride = align_up(blob_cap_for(pp), 256);
         seg_stride = align_up((2 * pp + 8) * 8, 256);
         sym_stride = align_up(tok_cap_for(pp) * 2, 256);
-        flag_stride = align_up(pp / 8 + 8, 256);
+        flag_stride = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
         int rc;
         if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
         if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
