@@ -717,8 +717,8 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 // Then the final states (last lane first), the end mark, the size gate and the prefix bytes,
 // and the N -> N/2 -> ... -> 1 fallback chain of multiframecompress.go:15-93.
 // LDS: stateTable as u16 (state - 2^tl).  grid = units, block = 1024, dynamic LDS = 2 << tl.
-#define TE_THREADS 1024
-#define TE_WAVES 16
+#define TE_THREADS 512              // two groups per CU (128 VGPRs each): the fix-up stalls of one overlap the other's work
+#define TE_WAVES 8
 #define TE_BLK 32                 // tokens per 64-byte block
 #define TE_RGRP 4                 // blocks per fix-up record
 #define TE_WARM 4                 // blocks of the predecessor's range walked as warm-up
@@ -986,7 +986,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
 }
 
 template <int TLHI>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI)
-__global__ void __launch_bounds__(TE_THREADS) k_enc_tans_wg(MicUnit *units) {
+__global__ void __launch_bounds__(TE_THREADS, 4) k_enc_tans_wg(MicUnit *units) {
     constexpr uint32_t tl_lo = (TLHI == 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ uint16_t s_stab[];
     __shared__ uint16_t s_E[TE_THREADS][8];
