@@ -141,6 +141,10 @@ int mic_hip_mic2_info(const uint8_t *compressed, size_t compressed_len,
 /* Replaces DecompressMultiFrame (multiframecompress.go:227) for independent-mode files. */
 int mic_hip_mic2_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *frames_out, size_t frames_cap_px);
+/* DecompressFrame(data, frameIdx) (multiframecompress.go:266-315) with ExtractFrame (multiframe.go:131-142):
+ * one frame of a MIC2 file; temporal files decode frames 0..frame_idx. */
+int mic_hip_mic2_decompress_frame(const uint8_t *compressed, size_t compressed_len, int frame_idx,
+                                  uint16_t *pixels_out, size_t pixels_cap);
 
 /* ---- WaveletV2 -------------------------------------------------------------------------------- */
 /* Replaces WaveletV2RLEFSECompressU16 and WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303,

@@ -87,6 +87,7 @@ ABI_SYMBOLS = [
     "mic_hip_compress_batch", "mic_hip_decompress_batch",
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
+    "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level",
@@ -132,6 +133,7 @@ def lib() -> C.CDLL:
     L.mic_hip_mic2_compress_temporal.argtypes = L.mic_hip_mic2_compress.argtypes
     L.mic_hip_mic2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.mic_hip_mic2_decompress_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
     L.mic_hip_wavelet_v2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -311,6 +313,20 @@ def decompress_multi_frame(compressed) -> np.ndarray:
     if rc:
         _raise(rc, "decompress_multi_frame")
     return out.reshape(n.value, h.value, w.value)
+
+
+def decompress_frame(compressed, frame_idx: int) -> np.ndarray:
+    """DecompressFrame (multiframecompress.go:266): one frame of a MIC2 file."""
+    c = _bytes_arr(compressed)
+    w, h, n, t = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_mic2_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(n), C.byref(t))
+    if rc:
+        _raise(rc, "decompress_frame")
+    out = np.empty(max(w.value, 0) * max(h.value, 0), dtype=np.uint16)
+    rc = lib().mic_hip_mic2_decompress_frame(c.ctypes.data, c.size, frame_idx, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "decompress_frame")
+    return out.reshape(h.value, w.value)
 
 
 # ------------------------------------------------------------------ WaveletV2

@@ -522,7 +522,7 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     if (w <= 0 || h <= 0 || n <= 0) return MIC_ERR_CORRUPT;
     size_t npx = (size_t)w * (size_t)h;
     if (npx * (size_t)n > frames_cap_px) return MIC_ERR_CAPACITY;
-    if (temporal) return mic2_temporal_decompress(c, len, w, h, n, frames_out);   // mic_temporal.hip
+    if (temporal) return mic2_temporal_decompress(c, len, w, h, n, n, frames_out);   // mic_temporal.hip
     size_t data_off = 20 + (size_t)n * 8;
     std::vector<mic_hip_dec_job> jobs((size_t)n);
     for (int i = 0; i < n; i++) {
@@ -535,6 +535,30 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     rc = mic_hip_decompress_batch(jobs.data(), n);
     if (rc) return rc;
     for (int i = 0; i < n; i++) if (jobs[(size_t)i].status != MIC_OK) return jobs[(size_t)i].status;
+    return MIC_OK;
+}
+
+// DecompressFrame (multiframecompress.go:266-315): one frame of a MIC2 file.  Independent mode decodes just that
+// frame; temporal mode needs frames 0..idx (all their residual streams are decoded at once, mic_temporal.hip).
+int mic_hip_mic2_decompress_frame(const uint8_t *c, size_t len, int frame_idx, uint16_t *pixels_out, size_t pixels_cap) {
+    if (!c || !pixels_out) return MIC_ERR_ARGS;
+    int w, h, n, temporal;
+    int rc = mic_hip_mic2_info(c, len, &w, &h, &n, &temporal);
+    if (rc) return rc;
+    if (frame_idx < 0 || frame_idx >= n) return MIC_ERR_ARGS;           // "frame index out of range"
+    if (w <= 0 || h <= 0) return MIC_ERR_CORRUPT;
+    const size_t npx = (size_t)w * (size_t)h;
+    if (npx > pixels_cap) return MIC_ERR_CAPACITY;
+    const size_t data_off = 20 + (size_t)n * 8;
+    if (!temporal) {
+        const size_t start = data_off + get_u32(c + 20 + (size_t)frame_idx * 8), bl = get_u32(c + 24 + (size_t)frame_idx * 8);
+        if (start + bl > len) return MIC_ERR_CORRUPT;                     // ExtractFrame, multiframe.go:131-142
+        return mic_hip_decompress_frame(c + start, bl, pixels_out, w, h);
+    }
+    std::vector<uint16_t> tmp(npx * (size_t)(frame_idx + 1));
+    rc = mic2_temporal_decompress(c, len, w, h, n, frame_idx + 1, tmp.data());
+    if (rc) return rc;
+    memcpy(pixels_out, tmp.data() + npx * (size_t)frame_idx, npx * 2);
     return MIC_OK;
 }
 

@@ -133,6 +133,6 @@ size_t unit_ws_bytes(size_t px);
 // MIC2 temporal pipeline (mic_temporal.hip)
 int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
                            uint8_t *out, size_t out_cap, size_t *out_len);
-int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n, uint16_t *frames_out);
+int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_total, int n, uint16_t *frames_out);
 constexpr size_t kWorkspaceBudget = (size_t)24 << 30;
 }  // namespace micapi

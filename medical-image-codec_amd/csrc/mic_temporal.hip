@@ -120,10 +120,10 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
     return MIC_OK;
 }
 
-int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n, uint16_t *frames_out) {
+int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_total, int n, uint16_t *frames_out) {
     const size_t npx = (size_t)w * (size_t)h;
     if (npx > ((size_t)1 << 28) || len > 0xFFFFFFF0ull) return MIC_ERR_UNSUPPORTED;
-    const size_t data_off = 20 + (size_t)n * 8;
+    const size_t data_off = 20 + (size_t)n_total * 8;                      // decodes frames 0 .. n-1 of n_total
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = ensure_device();
     if (rc) return rc;

@@ -169,6 +169,14 @@ def test_mic2_temporal_matches_oracle(mic, mico, synth, gpu_ready):
     # truncated residual stream
     with pytest.raises(mic.MicError):
         mic.decompress_multi_frame(want[:-3])
+    # DecompressFrame: any frame of either pipeline (multiframecompress.go:266-315)
+    rc, indep = mico.mic2_compress(stack, 4095, False)
+    rc, temp = mico.mic2_compress(stack, 4095, True)
+    for idx in (0, 3, 6):
+        assert np.array_equal(mic.decompress_frame(indep, idx), stack[idx])
+        assert np.array_equal(mic.decompress_frame(temp, idx), stack[idx])
+    with pytest.raises(mic.MicError):
+        mic.decompress_frame(temp, 7)
 
 
 def test_batch_mixed_shapes(mic, mico, synth, gpu_ready):
