@@ -196,6 +196,33 @@ def test_batch_mixed_shapes(mic, mico, synth, gpu_ready):
         assert st == 0 and np.array_equal(px, f)
 
 
+def test_decode_batch_of_mixed_flavours(mic, mico, synth, gpu_ready):
+    """One decode batch whose neighbouring units differ in every way the kernels specialise on: 2/4/8-state and rANS-free
+    1-state fallbacks, tableLog 13 next to tableLog 16, very different lengths, an odd unit count (the two-streams-per-wave
+    decoder pairs units 2w / 2w+1 and must leave a foreign or missing partner alone)."""
+    frames, blobs = [], []
+    specs = [(12, 300, 200, 2), (12, 260, 90, 4), (16, 256, 256, 2), (12, 500, 30, 8), (8, 256, 256, 2),
+             (12, 31, 9, 2), (16, 200, 180, 4), (10, 640, 64, 8), (12, 2577, 64, 2)]
+    for i, (depth, w, h, ns) in enumerate(specs):
+        img = synth.xr_like(cols=w, rows=h, depth=depth, seed=200 + i)
+        rc, blob = mico.compress_single_frame(img, (1 << depth) - 1, ns)
+        if rc != 0:
+            continue
+        frames.append(img); blobs.append(blob)
+    assert len(frames) >= 7
+    outs = mic.decompress_batch(blobs, [(f.shape[1], f.shape[0]) for f in frames])
+    for f, (st, px) in zip(frames, outs):
+        assert st == 0 and np.array_equal(px, f)
+    # the same units in reverse order (pairs differently)
+    outs = mic.decompress_batch(blobs[::-1], [(f.shape[1], f.shape[0]) for f in frames[::-1]])
+    for f, (st, px) in zip(frames[::-1], outs):
+        assert st == 0 and np.array_equal(px, f)
+    # drop the first unit: every pairing shifts by one
+    outs = mic.decompress_batch(blobs[1:], [(f.shape[1], f.shape[0]) for f in frames[1:]])
+    for f, (st, px) in zip(frames[1:], outs):
+        assert st == 0 and np.array_equal(px, f)
+
+
 def test_corrupt_stream_is_an_error_not_a_hang(mic, mico, gpu_ready):
     img = _mr()
     rc, blob = mico.compress_single_frame(img, int(img.max()), 2)
