@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         // ---- C: tokens owned by each position ---------------------------------------------------
         // k = 1-based index in the run, j = 1-based index in the stretch; rk = (k-3) % c, sj = (j-1) % c
         uint32_t k_in = 0, j_in = 0, rk_in = 0, sj_in = 0;     // state in front of position 0 (D replays the recurrence)
+        uint32_t bq = 0xFFFFu;                                  // fast path: position that opens a literal chunk (>= 8: none here)
         uint32_t tsum = 0;
         bool fast = false;                                      // 8 plain literals inside one chunk: the usual case in noisy data
         const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
@@ -401,10 +402,11 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
             uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
             uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
             k_in = k; j_in = j; rk_in = rk; sj_in = sj;
-            // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start, and the
-            // chunk neither starts nor ends here: sj + 1 .. sj + 8 stay inside [1, c - 2]
-            fast = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && sj + 10 <= c;
-            if (fast) tsum = TK_SPT;
+            // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start: eight literals of
+            // one stretch.  The only thing that can happen is a chunk boundary: position bq = c - 1 - sj opens a chunk
+            // (one more token: its header slot) and position bq - 1 closes one (it patches the header c tokens back).
+            fast = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && c >= 16;
+            if (fast) { bq = c - 1 - sj; tsum = TK_SPT + (bq < TK_SPT ? 1u : 0u); }
             else
 #pragma unroll
             for (int q = 0; q < TK_SPT; q++) {
@@ -436,12 +438,21 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         // ---- D: write ----------------------------------------------------------------------------
         if (fast) {
             const uint32_t pos = outp + toff + tincl - tsum;
-            if (pos + TK_SPT <= cap) {
+            if (pos + TK_SPT + 1 <= cap) {
                 typedef uint32_t tk_v4 __attribute__((ext_vector_type(4)));
                 typedef tk_v4 TkQ __attribute__((aligned(2)));
-                tk_v4 o;
-                o.x = v[3] | (v[4] << 16); o.y = v[5] | (v[6] << 16); o.z = v[7] | (v[8] << 16); o.w = v[9] | (v[10] << 16);
-                *(TkQ *)(tok + pos) = o;
+                if (bq >= TK_SPT) {
+                    tk_v4 o;
+                    o.x = v[3] | (v[4] << 16); o.y = v[5] | (v[6] << 16); o.z = v[7] | (v[8] << 16); o.w = v[9] | (v[10] << 16);
+                    *(TkQ *)(tok + pos) = o;
+                } else {                                         // header slot at pos + bq, patched by whoever closes that chunk
+#pragma unroll
+                    for (int q = 0; q < TK_SPT; q++) tok[pos + q + ((uint32_t)q >= bq ? 1u : 0u)] = (uint16_t)v[q + 3];
+                }
+                if (bq >= 1 && bq <= TK_SPT) {                   // position bq - 1 is the c-th literal of its chunk (next_starts)
+                    const uint32_t lit = pos + bq - 1;
+                    if (lit >= c) { tok[lit - c] = (uint16_t)(mid + c); count_tok(mid + c); } else s_ovf = 1;
+                }
                 uint32_t dmax = 0;                               // one window test for the 8 values
 #pragma unroll
                 for (int q = 0; q < TK_SPT; q++) dmax = max(dmax, v[q + 3] - hlo);
