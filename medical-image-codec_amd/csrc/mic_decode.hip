@@ -956,7 +956,9 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream, MicTime
     launch_tans_lds_class<N, ZB, 15>(d_units, n, stream);
     // tableLog 16 (16-bit depths): nextState fits 16 bits exactly when the table has no 0-bit entries, and the
     // 128 KiB table then takes a CU's LDS for one stream; streams with 0-bit entries go to k_dec_tans_gl
-    if (!ZB) launch_tans_lds_class<N, false, 16>(d_units, n, stream);
+    // One such stream fills a CU (7.7 ms per 256 CT frames, 30 us a frame); the L2-table kernel is ~4x slower per
+    // stream but holds 32 of them per CU, so very large batches are left to it.
+    if (!ZB && n <= 1280) launch_tans_lds_class<N, false, 16>(d_units, n, stream);
 }
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
