@@ -509,9 +509,12 @@ __global__ void __launch_bounds__(64) k_dec_tans_lds(MicUnit *units) {
 // state, and its stores and header walk are switched off.  Units of another class in a pair are left to the
 // single-stream kernels.  LDS bytes: ring A 0, stage A 1056, ring B 2048, stage B 3104, table A 3584, table B 19968.
 #define T2_TAB0 3584u
-#define T2_LDS (T2_TAB0 + 2u * 16384u)
+#define T2_WAVE 0x9000u                            // LDS bytes of one wave (its bits stay clear of the ring-index mask 0x3FC)
+#define T2_WAVES 4                                 // waves per group: one per SIMD by construction (four single-wave groups
+                                                   // landed two-on-a-SIMD on a third of the CUs, and the younger wave starves)
+#define T2_LDS (T2_WAVES * T2_WAVE)
 template <int N, bool ZB>
-__global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units) {
+__global__ void __launch_bounds__(64 * T2_WAVES) k_dec_tans_duo(MicUnit *units, int n_units) {
     extern __shared__ uint32_t s_mem[];
     typedef __attribute__((address_space(3))) uint32_t *l32;
     typedef __attribute__((address_space(3))) uint16_t *l16;
@@ -519,9 +522,13 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
     typedef const __attribute__((address_space(1))) uint32_t *gcu32;
     typedef __attribute__((address_space(1))) uint16_t *gu16;
     typedef uint32_t g_v2 __attribute__((ext_vector_type(2)));
-    const uint32_t lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+    // the waves of a group share nothing: each owns T2_WAVE bytes of LDS and never meets the others at a barrier
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+#ifdef MIC_STAMP
+    const uint64_t ck_entry = __builtin_amdgcn_s_memtime();
+#endif
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout below assumes dynamic LDS at 0
-    const int ui = (int)blockIdx.x * 2 + (int)half;
+    const int ui = ((int)blockIdx.x * T2_WAVES + (int)wv) * 2 + (int)half;
     bool mine = ui < n_units;
     MicUnit &u = units[mine ? ui : 0];
     uint32_t tl = 13, count = 0, len = 4, bits_off = 0;
@@ -536,7 +543,8 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
     }
     if (!__any(mine)) return;
     const uint32_t size = 1u << tl;
-    const uint32_t ringb = half << 11, stageb = 1056u + (half << 11), tabb = T2_TAB0 + (half << 14);
+    const uint32_t wbase = wv * T2_WAVE;
+    const uint32_t ringb = wbase + (half << 11), stageb = wbase + 1056u + (half << 11), tabb = wbase + T2_TAB0 + (half << 14);
     // ---- tables: u16 nextState = (newState + size) >> nbBits, 32 lanes per stream ----
     if (mine) {
         const uint32_t *dt = u.tt_nb;
@@ -573,7 +581,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
     { uint32_t a0, a1; load_blk(blk + 1, a0, a1); store_blk(blk + 1, a0, a1); load_blk(blk, a0, a1); store_blk(blk, a0, a1);
       load_blk(blk - 1, a0, a1); store_blk(blk - 1, a0, a1); }
     uint32_t pf0, pf1; load_blk(blk - 2, pf0, pf1);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   // wave-private LDS: the writes above are in before the reads below
     auto window = [&](int32_t qq) -> uint32_t {
         const uint32_t a = (((uint32_t)qq >> 3) & 0x3FCu) | ringb;
         const uint32_t w0 = *(l32)(uintptr_t)a, w1 = *(l32)(uintptr_t)(a + 4);
@@ -671,6 +679,9 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
                 });
         }
     };
+#ifdef MIC_STAMP
+    const uint64_t ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // the shorter half's true end-of-chunks state
     uint32_t sv_st[N]; int32_t sv_q = q;
 #pragma unroll
@@ -712,7 +723,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
         load_blk(blk + 1, a0, a1); store_blk(blk + 1, a0, a1);
         load_blk(blk, a0, a1); store_blk(blk, a0, a1);
         load_blk(blk - 1, a0, a1); store_blk(blk - 1, a0, a1);
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                   // wave-private LDS: the writes above are in before the reads below
     }
     // ---- tails: rem < 128 tokens per half, predicated per lane ----
     {
@@ -762,6 +773,9 @@ __global__ void __launch_bounds__(64) k_dec_tans_duo(MicUnit *units, int n_units
             });
         }
     }
+#ifdef MIC_STAMP
+    if (hl == 0 && mine) { u.dbg[8] = (uint32_t)(__builtin_amdgcn_s_memtime() - ck0); u.dbg[9] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0); u.dbg[10] = maxch; u.dbg[11] = (uint32_t)(ck0 - ck_entry); }
+#endif
     if (hl == 0 && mine) {
         if (q + 32 - (int32_t)(8u * sb) < 0) u.status = MICD_ERR_CORRUPT;   // bitreader.go:113-120
         else {
@@ -980,15 +994,15 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             duo_attr = true;
         }
-        const unsigned nw = (unsigned)((n + 1) / 2);
+        const unsigned nw = (unsigned)((n + 2 * T2_WAVES - 1) / (2 * T2_WAVES));
         if (t) t->mark("k_dec_tans_duo<2,false>");
-        hipLaunchKernelGGL((k_dec_tans_duo<2, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<2, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
         if (t) t->mark("k_dec_tans_duo<other>");
-        hipLaunchKernelGGL((k_dec_tans_duo<2, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
-        hipLaunchKernelGGL((k_dec_tans_duo<4, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
-        hipLaunchKernelGGL((k_dec_tans_duo<4, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
-        hipLaunchKernelGGL((k_dec_tans_duo<8, false>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
-        hipLaunchKernelGGL((k_dec_tans_duo<8, true>), dim3(nw), dim3(64), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<2, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<4, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<4, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<8, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
+        hipLaunchKernelGGL((k_dec_tans_duo<8, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
         launch_tans_lds<2, false>(d_units, n, stream, t, "k_dec_tans_lds<2,false,13>");
         launch_tans_lds<4, false>(d_units, n, stream, t, "k_dec_tans_lds<4,false,13>");
         launch_tans_lds<8, false>(d_units, n, stream, t, "k_dec_tans_lds<8,false,13>");
