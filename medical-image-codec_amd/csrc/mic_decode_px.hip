@@ -448,14 +448,20 @@ struct PrSlot {
 };
 
 // WIDE names the row-buffer class of the launch (a distinct instantiation has its own line in a kernel trace).
+// The ordinary class runs four units per group, one wave each with its own row buffer: a group's waves land on the four
+// SIMDs by construction, whereas single-wave groups pile up unevenly and the younger wave of a crowded SIMD starves.
 template <int WIDE>
-__global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, int w_hi) {
-    MicUnit &u = units[blockIdx.x];
+__global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units, int n_units, int w_lo, int w_hi) {
+    constexpr int WPG = WIDE ? 1 : 4;                            // waves (= units) per group
+    const int ui = (int)blockIdx.x * WPG + (int)(threadIdx.x >> 6);
+    if (ui >= n_units) return;
+    MicUnit &u = units[ui];
     if (u.status != MICD_OK || u.mode != 0) return;
     const int W = u.w, H = u.h;
     if (W <= w_lo || W > w_hi) return;
-    extern __shared__ uint32_t s_rowbuf[];                       // ngrp x PR_DW dwords
-    const uint32_t lane = threadIdx.x;
+    extern __shared__ uint32_t s_rowbuf_all[];                   // per wave: ngrp x PR_DW dwords
+    uint32_t *const s_rowbuf = s_rowbuf_all + (WIDE ? 0u : (threadIdx.x >> 6) * 4096u);   // 16 KiB per wave (8192 columns)
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
     const uint32_t thr = u.dec_thr;
     const pr_gu16 px = (pr_gu16)u.px_out;
@@ -469,7 +475,7 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
     {
         uint16_t *row16 = (uint16_t *)s_rowbuf;
         for (int x = (int)lane; x < ngrp * PR_K; x += 64) row16[x] = (x < W) ? px[x] : (uint16_t)0;
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                          // wave-private LDS: writes above land before the reads below
         const int cw = (W + 63) >> 6;
         const int x0 = min(W, (int)lane * cw), x1 = min(W, x0 + cw);
         uint32_t rs = 0, sum = 0;
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(64) k_dec_predict(MicUnit *units, int w_lo, in
             cur = raw ? v : ((cur + v - thr) & 0xFFFFu);
             row16[x] = (uint16_t)cur;
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                          // wave-private LDS: writes above land before the reads below
     }
 
     // ---- the pipeline ----
@@ -602,7 +608,7 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
     // two row-buffer classes so that ordinary widths keep many waves per CU
     if (t) t->mark("k_dec_predict<0>");
-    hipLaunchKernelGGL(k_dec_predict<0>, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - PR_K);
+    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 0, 8192 - PR_K);
     if (t) t->mark("k_dec_predict<wide>");
-    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, 8192 - PR_K, PR_MAX_W);
+    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W);
 }
