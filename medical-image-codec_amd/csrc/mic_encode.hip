@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_WAVES 8
 #define TE_BLK 32                 // tokens per 64-byte block
 #define TE_RGRP 4                 // blocks per fix-up record
-#define TE_WARM 4                 // blocks of the predecessor's range walked as warm-up
+#define TE_WARM 12                // blocks of the predecessor's range walked as warm-up
 #define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
 
 // One block of 32 tokens / 32 recorded states as four 16-byte vectors.
