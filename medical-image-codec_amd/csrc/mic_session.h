@@ -55,7 +55,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 using namespace micapi;
 
 struct mic_hip_session {
-    int max_units = 0; size_t max_px = 0;
+    int max_units = 0; size_t max_px = 0;   // shape of the current workspace layout (see ensure)
     hipStream_t stream = nullptr;
     DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
     DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
@@ -69,8 +69,11 @@ struct mic_hip_session {
 
     int ensure(int n, size_t px) {
         if (!stream) HIP_TRY(hipStreamCreate(&stream));
-        if (n <= max_units && px <= max_px) return MIC_OK;
-        int nn = std::max(n, max_units); size_t pp = std::max(px, max_px);
+        // The workspace takes the shape of the current call (n units of up to px pixels); buffers only ever grow.  Sizing
+        // for max(n) x max(px) over a session's history would ask for the bounding box of unrelated calls (one 4-megapixel
+        // wavelet frame, then 3000 WSI planes of 256 x 256).
+        if (n == max_units && px == max_px) return MIC_OK;
+        int nn = n; size_t pp = px;
         tok_stride = align_up(tok_cap_for(pp) * 2, 256);
         blob_stride = align_up(blob_cap_for(pp), 256);
         seg_stride = align_up((2 * pp + 8) * 8, 256);
