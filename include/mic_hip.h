@@ -179,6 +179,11 @@ int mic_hip_wsi_decompress_tile(const uint8_t *compressed, size_t compressed_len
 /* All tiles of one pyramid level in a single batch, stitched into a level-sized RGB image. */
 int mic_hip_wsi_decompress_level(const uint8_t *compressed, size_t compressed_len, int level,
                                  uint8_t *rgb_out, size_t out_cap);
+/* DecompressWSIRegion(data, level, x, y, w, h) (wsicompress.go:219-297): a rectangle of one pyramid level; w and h are
+ * clamped to the level as the reference does and returned through out_w / out_h (may be NULL). */
+int mic_hip_wsi_decompress_region(const uint8_t *compressed, size_t compressed_len, int level,
+                                  int x, int y, int w, int h,
+                                  uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h);
 
 /* ---- device-resident sessions (inputs and outputs stay in HBM) ------------------------------ */
 /* A session owns the workspace for up to max_units units of up to max_px pixels each and

@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
-    "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level",
+    "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
     "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
     "mic_hip_session_encode", "mic_hip_session_decode",
     "mic_hip_session_encode_enqueue", "mic_hip_session_encode_finish",
@@ -142,6 +142,8 @@ def lib() -> C.CDLL:
     L.mic_hip_wsi_level_info.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wsi_decompress_tile.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mic_hip_wsi_decompress_level.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+    L.mic_hip_wsi_decompress_region.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mic_hip_session_encode_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Unit), C.c_int]
     L.mic_hip_session_encode_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -402,6 +404,17 @@ def decompress_wsi_tile(compressed, level: int, tile_x: int, tile_y: int) -> np.
     if rc:
         _raise(rc, "decompress_wsi_tile")
     return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()
+
+
+def decompress_wsi_region(compressed, level: int, x: int, y: int, w: int, h: int) -> np.ndarray:
+    """DecompressWSIRegion (wsicompress.go:219): (h', w', 3) uint8, clamped to the level."""
+    c = _bytes_arr(compressed)
+    out = np.empty(max(w, 0) * max(h, 0) * 3, dtype=np.uint8)
+    ow, oh = C.c_int(), C.c_int()
+    rc = lib().mic_hip_wsi_decompress_region(c.ctypes.data, c.size, level, x, y, w, h, out.ctypes.data, out.size, C.byref(ow), C.byref(oh))
+    if rc:
+        _raise(rc, "decompress_wsi_region")
+    return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3)
 
 
 def decompress_wsi_level(compressed, level: int = 0) -> np.ndarray:

@@ -391,4 +391,42 @@ int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_
     return decode_tiles(c, len, m, tiles, place, rgb_out, L.w, L.h);
 }
 
+// DecompressWSIRegion (wsicompress.go:219-297): the tiles that overlap the rectangle are decoded in one batch into
+// their tile-aligned bounding box, the rectangle is cut out of it.  w / h are clamped to the level like the reference does.
+int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x, int y, int w, int h,
+                                  uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) {
+    if (!c || !rgb_out) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (level < 0 || level >= m.nlev || x < 0 || y < 0) return MIC_ERR_ARGS;
+    const Level &L = m.lv[(size_t)level];
+    if (L.w <= 0 || L.h <= 0 || m.tw <= 0 || m.th <= 0) return MIC_ERR_CORRUPT;
+    if ((size_t)L.tx * m.tw < (size_t)L.w || (size_t)L.ty * m.th < (size_t)L.h) return MIC_ERR_CORRUPT;
+    if ((int64_t)x + w > L.w) w = L.w - x;                                                  // :232-237
+    if ((int64_t)y + h > L.h) h = L.h - y;
+    if (w <= 0 || h <= 0) return MIC_ERR_ARGS;                                              // "MIC3: empty region"
+    if ((size_t)w * h * 3 > out_cap) return MIC_ERR_CAPACITY;
+    const int tx0 = x / m.tw, ty0 = y / m.th, tx1 = (x + w - 1) / m.tw, ty1 = (y + h - 1) / m.th;
+    const int bx = tx0 * m.tw, by = ty0 * m.th;
+    const int bw = std::min((tx1 + 1) * m.tw, L.w) - bx, bh = std::min((ty1 + 1) * m.th, L.h) - by;
+    std::vector<size_t> tiles; std::vector<int4> place;
+    for (int ty = ty0; ty <= ty1; ty++) for (int tx = tx0; tx <= tx1; tx++) {
+        const int aw = std::min(m.tw, L.w - tx * m.tw), ah = std::min(m.th, L.h - ty * m.th);
+        if (aw <= 0 || ah <= 0) continue;
+        tiles.push_back((size_t)L.first + (size_t)ty * L.tx + tx);
+        place.push_back(make_int4(tx * m.tw - bx, ty * m.th - by, aw, ah));
+    }
+    std::vector<uint8_t> box((size_t)bw * bh * 3);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((rc = ensure_device())) return rc;
+        if ((rc = decode_tiles(c, len, m, tiles, place, box.data(), bw, bh))) return rc;
+    }
+    for (int r = 0; r < h; r++)
+        memcpy(rgb_out + (size_t)r * w * 3, box.data() + ((size_t)(y - by + r) * bw + (size_t)(x - bx)) * 3, (size_t)w * 3);
+    if (out_w) *out_w = w;
+    if (out_h) *out_h = h;
+    return MIC_OK;
+}
+
 }  // extern "C"

@@ -403,6 +403,24 @@ def test_wsi_matches_oracle_and_round_trips(mic, mico, synth, gpu_ready):
                 assert np.array_equal(mic.decompress_wsi_tile(got, lvl, tx, ty), t)
 
 
+def test_wsi_region_matches_the_slide(mic, synth, gpu_ready):
+    """DecompressWSIRegion (wsicompress.go:219-297): rectangles inside a tile, across tile borders, clamped at the edge,
+    on level 0 (= the original pixels: the codec is lossless) and on level 1 (= the same cut of the whole-level decode)."""
+    W, H = 700, 520
+    slide = synth.wsi_like(W, H, seed=9)
+    blob = mic.compress_wsi(slide, W, H, tile_w=256, tile_h=256, levels=2)
+    for (x, y, w, h) in [(10, 20, 100, 60), (200, 200, 200, 200), (0, 0, W, H), (600, 400, 300, 300), (255, 255, 2, 2)]:
+        got = mic.decompress_wsi_region(blob, 0, x, y, w, h)
+        assert np.array_equal(got, slide[y:y + h, x:x + w])
+    lv1 = mic.decompress_wsi_level(blob, 1).reshape(H // 2, W // 2, 3)
+    got = mic.decompress_wsi_region(blob, 1, 100, 50, 200, 150)
+    assert np.array_equal(got, lv1[50:200, 100:300])
+    with pytest.raises(mic.MicError):
+        mic.decompress_wsi_region(blob, 0, W, 0, 10, 10)            # empty after clamping
+    with pytest.raises(mic.MicError):
+        mic.decompress_wsi_region(blob, 5, 0, 0, 10, 10)
+
+
 def test_wsi_white_slide_is_101_bytes(mic, gpu_ready):
     white = np.full((256, 256, 3), 255, dtype=np.uint8)
     blob = mic.compress_wsi(white, 256, 256)
