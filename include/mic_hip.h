@@ -167,16 +167,25 @@ int mic_hip_wavelet_v2_decompress(const uint8_t *compressed, size_t compressed_l
  * plane's CompressSingleFrame run on the device; the host writes the container. */
 int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
                          uint8_t *out, size_t out_cap, size_t *out_len);
+/* CompressWSI(pixels, width, height, channels, bitsPerSample, opts) with the reference's full signature: channels 3 /
+ * 8 bits is the call above; channels 1 with 8 or 16 bits per sample (16-bit samples little-endian, bytesToUint16Slice,
+ * wsicompress.go:573-587) is the greyscale path -- Downsample2xGrey (wsipyramid.go:34-55), one plane per tile and the tile blob is
+ * that plane's blob (compressGreyTileBlob, :366-370), no colour-transform flag.  Other combinations: MIC_ERR_UNSUPPORTED. */
+int mic_hip_wsi_compress_ex(const uint8_t *pixels, int width, int height, int channels, int bits_per_sample,
+                            int tile_w, int tile_h, int levels, uint8_t *out, size_t out_cap, size_t *out_len);
+/* WSIHeader.Channels / BitsPerSample / ColorTransform (wsiformat.go:169-227).  The decompress calls below write
+ * channels * (bits_per_sample == 16 ? 2 : 1) bytes per pixel. */
+int mic_hip_wsi_format(const uint8_t *compressed, size_t compressed_len, int *channels, int *bits_per_sample, int *color_transform);
 /* ReadWSIHeader (wsicompress.go:299). */
 int mic_hip_wsi_info(const uint8_t *compressed, size_t compressed_len, int *width, int *height,
                      int *tile_w, int *tile_h, int *levels, uint64_t *total_tiles);
 int mic_hip_wsi_level_info(const uint8_t *compressed, size_t compressed_len, int level,
                            int *width, int *height, int *tiles_x, int *tiles_y);
 /* Replaces DecompressWSITile (wsicompress.go:175): one tile, cropped at the level's edge;
- * *out_w x *out_h x 3 bytes are written. */
+ * *out_w x *out_h pixels are written (3 bytes each for RGB, 1 or 2 for greyscale). */
 int mic_hip_wsi_decompress_tile(const uint8_t *compressed, size_t compressed_len, int level, int tile_x, int tile_y,
                                 uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h);
-/* All tiles of one pyramid level in a single batch, stitched into a level-sized RGB image. */
+/* All tiles of one pyramid level in a single batch, stitched into a level-sized image. */
 int mic_hip_wsi_decompress_level(const uint8_t *compressed, size_t compressed_len, int level,
                                  uint8_t *rgb_out, size_t out_cap);
 /* DecompressWSIRegion(data, level, x, y, w, h) (wsicompress.go:219-297): a rectangle of one pyramid level; w and h are

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
-    "mic_hip_wsi_compress", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
+    "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
     "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
     "mic_hip_session_encode", "mic_hip_session_decode",
@@ -138,6 +138,8 @@ def lib() -> C.CDLL:
     L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_wsi_compress_ex.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_wsi_format.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 3
     L.mic_hip_wsi_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.c_uint64)]
     L.mic_hip_wsi_level_info.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wsi_decompress_tile.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -363,69 +365,92 @@ def wavelet_v2_decompress(compressed) -> Tuple[np.ndarray, int, int]:
 # ------------------------------------------------------------------ MIC3 / WSI
 def compress_wsi(pixels, width: int, height: int, channels: int = 3, bits_per_sample: int = 8,
                  tile_w: int = 0, tile_h: int = 0, levels: int = 0) -> bytes:
-    """CompressWSI (wsicompress.go:27) for 8-bit RGB."""
-    if channels != 3 or bits_per_sample != 8:
-        raise MicError(MIC_ERR_UNSUPPORTED, "compress_wsi: only 8-bit RGB")
-    px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
-    if px.size != width * height * 3:
+    """CompressWSI (wsicompress.go:27): 8-bit RGB, or greyscale (channels=1) with 8 or 16 bits per sample.
+    Like the reference, pixels is the raw byte image; a uint16 array is taken as little-endian 16-bit samples."""
+    if not ((channels == 3 and bits_per_sample == 8) or (channels == 1 and bits_per_sample in (8, 16))):
+        raise MicError(MIC_ERR_UNSUPPORTED, "compress_wsi: 8-bit RGB or 8/16-bit greyscale")
+    arr = np.asarray(pixels)
+    if arr.dtype == np.uint16:
+        arr = arr.astype("<u2", copy=False)
+    px = np.ascontiguousarray(arr).reshape(-1).view(np.uint8) if arr.dtype.itemsize == 2 else np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+    bpp = channels * (2 if bits_per_sample == 16 else 1)
+    if px.size != width * height * bpp:
         raise MicError(MIC_ERR_ARGS, "compress_wsi")
     cap = px.size * 3 + (1 << 20)
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
-    rc = lib().mic_hip_wsi_compress(px.ctypes.data, width, height, tile_w, tile_h, levels, out.ctypes.data, cap, C.byref(n))
+    rc = lib().mic_hip_wsi_compress_ex(px.ctypes.data, width, height, channels, bits_per_sample, tile_w, tile_h, levels,
+                                       out.ctypes.data, cap, C.byref(n))
     if rc:
         _raise(rc, "compress_wsi")
     return out[: n.value].tobytes()
 
 
 def read_wsi_header(compressed):
-    """ReadWSIHeader (wsicompress.go:299): dict with the level table."""
+    """ReadWSIHeader (wsicompress.go:299): dict with the format and the level table."""
     c = _bytes_arr(compressed)
     w, h, tw, th, nl = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
     tot = C.c_uint64()
     rc = lib().mic_hip_wsi_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(tw), C.byref(th), C.byref(nl), C.byref(tot))
     if rc:
         _raise(rc, "read_wsi_header")
+    ch, bps, ct = C.c_int(), C.c_int(), C.c_int()
+    lib().mic_hip_wsi_format(c.ctypes.data, c.size, C.byref(ch), C.byref(bps), C.byref(ct))
     levels = []
     for i in range(nl.value):
         lw, lh, tx, ty = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib().mic_hip_wsi_level_info(c.ctypes.data, c.size, i, C.byref(lw), C.byref(lh), C.byref(tx), C.byref(ty))
         levels.append(dict(width=lw.value, height=lh.value, tiles_x=tx.value, tiles_y=ty.value))
-    return dict(width=w.value, height=h.value, tile_width=tw.value, tile_height=th.value, total_tiles=tot.value, levels=levels)
+    return dict(width=w.value, height=h.value, tile_width=tw.value, tile_height=th.value, total_tiles=tot.value,
+                channels=ch.value, bits_per_sample=bps.value, color_transform=bool(ct.value), levels=levels)
+
+
+def _wsi_shape(hdr, out: np.ndarray, w: int, h: int) -> np.ndarray:
+    """bytes -> (h, w, 3) uint8 for RGB, (h, w) uint8 / uint16 for greyscale (uint16ToBytes, wsicompress.go:589-603)."""
+    if hdr["channels"] == 3:
+        return out[: w * h * 3].reshape(h, w, 3)
+    if hdr["bits_per_sample"] == 16:
+        return out[: w * h * 2].view("<u2").reshape(h, w)
+    return out[: w * h].reshape(h, w)
+
+
+def _wsi_bpp(hdr) -> int:
+    return hdr["channels"] * (2 if hdr["bits_per_sample"] == 16 else 1)
 
 
 def decompress_wsi_tile(compressed, level: int, tile_x: int, tile_y: int) -> np.ndarray:
-    """DecompressWSITile (wsicompress.go:175): cropped (h, w, 3) uint8."""
+    """DecompressWSITile (wsicompress.go:175): the tile cropped at the level's edge."""
     c = _bytes_arr(compressed)
     hdr = read_wsi_header(c)
-    out = np.empty(hdr["tile_width"] * hdr["tile_height"] * 3, dtype=np.uint8)
+    out = np.empty(hdr["tile_width"] * hdr["tile_height"] * _wsi_bpp(hdr), dtype=np.uint8)
     ow, oh = C.c_int(), C.c_int()
     rc = lib().mic_hip_wsi_decompress_tile(c.ctypes.data, c.size, level, tile_x, tile_y, out.ctypes.data, out.size, C.byref(ow), C.byref(oh))
     if rc:
         _raise(rc, "decompress_wsi_tile")
-    return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3).copy()
+    return _wsi_shape(hdr, out, ow.value, oh.value).copy()
 
 
 def decompress_wsi_region(compressed, level: int, x: int, y: int, w: int, h: int) -> np.ndarray:
-    """DecompressWSIRegion (wsicompress.go:219): (h', w', 3) uint8, clamped to the level."""
+    """DecompressWSIRegion (wsicompress.go:219): the rectangle clamped to the level."""
     c = _bytes_arr(compressed)
-    out = np.empty(max(w, 0) * max(h, 0) * 3, dtype=np.uint8)
+    hdr = read_wsi_header(c)
+    out = np.empty(max(w, 0) * max(h, 0) * _wsi_bpp(hdr), dtype=np.uint8)
     ow, oh = C.c_int(), C.c_int()
     rc = lib().mic_hip_wsi_decompress_region(c.ctypes.data, c.size, level, x, y, w, h, out.ctypes.data, out.size, C.byref(ow), C.byref(oh))
     if rc:
         _raise(rc, "decompress_wsi_region")
-    return out[: ow.value * oh.value * 3].reshape(oh.value, ow.value, 3)
+    return _wsi_shape(hdr, out, ow.value, oh.value)
 
 
 def decompress_wsi_level(compressed, level: int = 0) -> np.ndarray:
     c = _bytes_arr(compressed)
     hdr = read_wsi_header(c)
     lv = hdr["levels"][level]
-    out = np.empty(lv["width"] * lv["height"] * 3, dtype=np.uint8)
+    out = np.empty(lv["width"] * lv["height"] * _wsi_bpp(hdr), dtype=np.uint8)
     rc = lib().mic_hip_wsi_decompress_level(c.ctypes.data, c.size, level, out.ctypes.data, out.size)
     if rc:
         _raise(rc, "decompress_wsi_level")
-    return out.reshape(lv["height"], lv["width"], 3)
+    return _wsi_shape(hdr, out, lv["width"], lv["height"])
 
 
 # ------------------------------------------------------------------ device-resident sessions

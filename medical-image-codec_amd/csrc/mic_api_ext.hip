@@ -1,4 +1,5 @@
 // mic_api_ext.hip -- MIC3 / WSI on the GPU (wsicompress.go, wsiformat.go, wsipyramid.go, ycocgr.go).
+// 8-bit RGB slides (three YCoCg-R planes per tile) and 8/16-bit greyscale slides (one plane per tile).
 //
 // CompressWSI = pyramid (2x2 box) -> zero-padded tiles -> YCoCg-R -> three planes per tile ->
 // per plane: constant-zero / constant / CompressSingleFrame / raw fallback -> tile blobs -> MIC3.
@@ -87,6 +88,52 @@ __global__ void __launch_bounds__(256) k_wsi_planes_to_rgb(const uint16_t *plane
     }
 }
 
+// Greyscale slides (channels = 1, 8 or 16 bits per sample; T = the sample type, little-endian like bytesToUint16Slice,
+// wsicompress.go:573-603).  Downsample2xGrey (wsipyramid.go:34-55) works on the samples widened to u16.
+template <typename T>
+__global__ void __launch_bounds__(256) k_wsi_downsample_grey(const T *src, int sw, T *dst, int dw, int dh) {
+    const size_t n = (size_t)dw * dh;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % dw), y = (int)(i / dw);
+        const size_t a = (size_t)(2 * y) * sw + 2 * x, d = a + (size_t)sw;
+        dst[i] = (T)(((uint32_t)src[a] + src[a + 1] + src[d] + src[d + 1] + 2) / 4);
+    }
+}
+
+// extractTileRGB for one channel + bytesToUint16Slice + the constant / max scan.  planes: [tile][tw*th] u16 ; stats: [tile] {min, max}
+template <typename T>
+__global__ void __launch_bounds__(256) k_wsi_tile_plane_grey(const T *img, int iw, int ih, int tw, int th, int tiles_x,
+                                                           int tile_base, uint16_t *planes, uint32_t *stats) {
+    const int tile = blockIdx.y;
+    const int tx = (tile + tile_base) % tiles_x, ty = (tile + tile_base) / tiles_x;
+    const size_t npx = (size_t)tw * th;
+    uint16_t *pl = planes + (size_t)tile * npx;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % tw), y = (int)(i / tw);
+        const int sx = tx * tw + x, sy = ty * th + y;
+        const uint32_t v = (sx < iw && sy < ih) ? (uint32_t)img[(size_t)sy * iw + sx] : 0u;
+        pl[i] = (uint16_t)v;
+        mn = min(mn, v); mx = max(mx, v);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&stats[(size_t)tile * 2], mn); atomicMax(&stats[(size_t)tile * 2 + 1], mx); }
+}
+
+// uint16ToBytes (wsicompress.go:589-603) + cropTile: the plane of tile `t` -> dst image region
+template <typename T>
+__global__ void __launch_bounds__(256) k_wsi_plane_to_grey(const uint16_t *planes, int tw, int th, const int4 *place, T *dst, int dst_w) {
+    const int tile = blockIdx.y;
+    const int4 pl = place[tile];
+    const uint16_t *src = planes + (size_t)tile * tw * th;
+    const size_t n = (size_t)pl.z * pl.w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % pl.z), y = (int)(i / pl.z);
+        dst[(size_t)(pl.y + y) * dst_w + (pl.x + x)] = (T)src[(size_t)y * tw + x];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_fill_u16(uint16_t *p, size_t n, uint16_t v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -111,6 +158,11 @@ std::vector<Level> plan_levels(int w, int h, int tw, int th, int req) {
 struct Mic3 {
     int w, h, tw, th, channels, bps, flags, nlev; uint64_t total; size_t data_off;
     std::vector<Level> lv;
+    bool rgb() const { return channels == 3 && bps == 8; }                    // compressTileBlob / decompressTileBlob, wsicompress.go:312-317, :424-429
+    bool grey() const { return channels == 1 && (bps == 8 || bps == 16); }
+    bool supported() const { return (rgb() && (flags & 0x02)) || grey(); }
+    int planes() const { return rgb() ? 3 : 1; }
+    size_t bpp() const { return (size_t)channels * (bps == 16 ? 2 : 1); }  // bytesPerPixel, wsicompress.go:530-533
 };
 int parse_mic3(const uint8_t *c, size_t len, Mic3 &m) {                       // ReadMIC3Header, wsiformat.go:169-227
     if (len < 48 || memcmp(c, "MIC3", 4) != 0) return MIC_ERR_CORRUPT;
@@ -129,22 +181,23 @@ int parse_mic3(const uint8_t *c, size_t len, Mic3 &m) {                       //
     return MIC_OK;
 }
 
-// decode the given tiles (global indices) of one level into dst (an image of dst_w x dst_h RGB);
+// decode the given tiles (global indices) of one level into dst (an image of dst_w x dst_h pixels of the slide's format);
 // place[k] = where tile k goes and how much of it is kept
 int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<size_t> &tiles, const std::vector<int4> &place,
                  uint8_t *rgb_out, int dst_w, int dst_h) {
-    if (m.channels != 3 || m.bps != 8 || !(m.flags & 0x02)) return MIC_ERR_UNSUPPORTED;
+    if (!m.supported()) return MIC_ERR_UNSUPPORTED;
     mic_hip_session *s = &g_default;
     const size_t npx = (size_t)m.tw * m.th;
     const size_t ntile = tiles.size();
+    const size_t P = (size_t)m.planes(), bpp = m.bpp();
     // per-tile chunking keeps the unit workspace bounded
-    const size_t per = std::max<size_t>(1, kWorkspaceBudget / (3 * unit_ws_bytes(npx)));
+    const size_t per = std::max<size_t>(1, kWorkspaceBudget / (P * unit_ws_bytes(npx)));
     DevBuf planes, d_place, d_out;
     int rc;
-    if ((rc = d_out.reserve((size_t)dst_w * dst_h * 3 + 64))) return rc;
+    if ((rc = d_out.reserve((size_t)dst_w * dst_h * bpp + 64))) return rc;
     for (size_t t0 = 0; t0 < ntile && rc == MIC_OK; t0 += per) {
         const size_t nt = std::min(per, ntile - t0);
-        if ((rc = planes.reserve(nt * 3 * npx * 2 + 64))) break;
+        if ((rc = planes.reserve(nt * P * npx * 2 + 64))) break;
         if ((rc = d_place.reserve(nt * sizeof(int4) + 64))) break;
         if ((rc = s->ensure(1, npx))) break;
         std::vector<mic_hip_unit> units; std::vector<uint64_t> offs(1, 0); std::vector<uint8_t> comp;
@@ -155,14 +208,18 @@ int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<
             if (gi >= m.total) { rc = MIC_ERR_CORRUPT; break; }
             const uint8_t *e = c + 48 + 20 * (size_t)m.nlev + 16 * gi;
             const uint64_t bo = get_u64(e), bl = get_u64(e + 8);
-            if (m.data_off + bo + bl > len || bl < 12) { rc = MIC_ERR_CORRUPT; break; }   // ExtractTileBlob, wsiformat.go:230-241
+            if (m.data_off + bo + bl > len) { rc = MIC_ERR_CORRUPT; break; }              // ExtractTileBlob, wsiformat.go:230-241
             const uint8_t *blob = c + m.data_off + bo;
-            const size_t l0 = get_u32(blob), l1 = get_u32(blob + 4), l2 = get_u32(blob + 8);
-            if (12 + l0 + l1 + l2 > bl) { rc = MIC_ERR_CORRUPT; break; }                   // wsicompress.go:440-442
-            const size_t pl_off[3] = { 12, 12 + l0, 12 + l0 + l1 }, pl_len[3] = { l0, l1, l2 };
-            for (int p = 0; p < 3; p++) {                                                  // decompressWSIPlane, :464-500
+            size_t pl_off[3] = { 0, 0, 0 }, pl_len[3] = { (size_t)bl, 0, 0 };              // greyscale: the blob is the plane, :477-484
+            if (P == 3) {
+                if (bl < 12) { rc = MIC_ERR_CORRUPT; break; }
+                const size_t l0 = get_u32(blob), l1 = get_u32(blob + 4), l2 = get_u32(blob + 8);
+                if (12 + l0 + l1 + l2 > bl) { rc = MIC_ERR_CORRUPT; break; }               // wsicompress.go:440-442
+                pl_off[0] = 12; pl_off[1] = 12 + l0; pl_off[2] = 12 + l0 + l1; pl_len[0] = l0; pl_len[1] = l1; pl_len[2] = l2;
+            }
+            for (size_t p = 0; p < P; p++) {                                               // decompressWSIPlane, :487-527
                 const uint8_t *d = blob + pl_off[p]; const size_t dl = pl_len[p];
-                const size_t plane = k * 3 + (size_t)p;
+                const size_t plane = k * P + p;
                 if (dl == 0) { rc = MIC_ERR_CORRUPT; break; }
                 if (d[0] == 0) fills.push_back(Fill{ plane, 0, 0, nullptr });
                 else if (d[0] == 1) { if (dl < 3) { rc = MIC_ERR_CORRUPT; break; } fills.push_back(Fill{ plane, 1, (uint16_t)(d[1] | (d[2] << 8)), nullptr }); }
@@ -190,13 +247,20 @@ int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<
             if (rc) break;
         }
         HIP_TRY(hipMemcpyAsync(d_place.p, place.data() + t0, nt * sizeof(int4), hipMemcpyHostToDevice, s->stream));
-        hipLaunchKernelGGL(k_wsi_planes_to_rgb, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place.p,
-                           (uint8_t *)d_out.p, dst_w);
+        if (P == 3)
+            hipLaunchKernelGGL(k_wsi_planes_to_rgb, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place.p,
+                               (uint8_t *)d_out.p, dst_w);
+        else if (m.bps == 16)
+            hipLaunchKernelGGL(k_wsi_plane_to_grey<uint16_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th,
+                               (const int4 *)d_place.p, (uint16_t *)d_out.p, dst_w);
+        else
+            hipLaunchKernelGGL(k_wsi_plane_to_grey<uint8_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th,
+                               (const int4 *)d_place.p, (uint8_t *)d_out.p, dst_w);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (rc == MIC_OK) {
-        hipError_t e = hipMemcpy(rgb_out, d_out.p, (size_t)dst_w * dst_h * 3, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(rgb_out, d_out.p, (size_t)dst_w * dst_h * bpp, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = MIC_ERR_DEVICE;
     }
     planes.release(); d_place.release(); d_out.release();
@@ -207,10 +271,13 @@ int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<
 
 extern "C" {
 
-// CompressWSI for 8-bit RGB (wsicompress.go:27-171)
-int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
-                         uint8_t *out, size_t out_cap, size_t *out_len) {
+// CompressWSI (wsicompress.go:27-171): 8-bit RGB (channels 3) or 8/16-bit greyscale (channels 1, little-endian samples)
+int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int channels, int bits_per_sample, int tile_w, int tile_h,
+                            int levels, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!rgb || !out || !out_len || width <= 0 || height <= 0 || tile_w < 0 || tile_h < 0) return MIC_ERR_ARGS;
+    Mic3 fmt; fmt.channels = channels; fmt.bps = bits_per_sample; fmt.flags = 0x01 | (channels == 3 ? 0x02 : 0);   // defaults(), wsiformat.go:86-96
+    if (!fmt.supported()) return MIC_ERR_UNSUPPORTED;
+    const size_t P = (size_t)fmt.planes(), bpp = fmt.bpp();
     if (tile_w == 0) tile_w = 256;                                                          // WSIOptions.defaults, wsiformat.go:86-96
     if (tile_h == 0) tile_h = 256;
     if ((size_t)tile_w * tile_h > ((size_t)1 << 26) || levels > 32) return MIC_ERR_UNSUPPORTED;
@@ -230,34 +297,48 @@ int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, 
     std::vector<DevBuf> img((size_t)nlev);
     DevBuf planes, stats;
     auto cleanup = [&]() { for (auto &b : img) b.release(); planes.release(); stats.release(); };
-    if ((rc = img[0].reserve((size_t)width * height * 3 + 64))) { cleanup(); return rc; }
-    if (hipMemcpyAsync(img[0].p, rgb, (size_t)width * height * 3, hipMemcpyHostToDevice, s->stream) != hipSuccess) { cleanup(); return MIC_ERR_DEVICE; }
+    if ((rc = img[0].reserve((size_t)width * height * bpp + 64))) { cleanup(); return rc; }
+    if (hipMemcpyAsync(img[0].p, rgb, (size_t)width * height * bpp, hipMemcpyHostToDevice, s->stream) != hipSuccess) { cleanup(); return MIC_ERR_DEVICE; }
     for (int i = 1; i < nlev; i++) {
-        if ((rc = img[(size_t)i].reserve((size_t)lv[i].w * lv[i].h * 3 + 64))) { cleanup(); return rc; }
-        hipLaunchKernelGGL(k_wsi_downsample, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)i - 1].p, lv[i - 1].w,
-                           (uint8_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
+        if ((rc = img[(size_t)i].reserve((size_t)lv[i].w * lv[i].h * bpp + 64))) { cleanup(); return rc; }
+        if (P == 3)
+            hipLaunchKernelGGL(k_wsi_downsample, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)i - 1].p, lv[i - 1].w,
+                               (uint8_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
+        else if (bits_per_sample == 16)
+            hipLaunchKernelGGL(k_wsi_downsample_grey<uint16_t>, dim3(1024), dim3(256), 0, s->stream, (const uint16_t *)img[(size_t)i - 1].p,
+                               lv[i - 1].w, (uint16_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
+        else
+            hipLaunchKernelGGL(k_wsi_downsample_grey<uint8_t>, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)i - 1].p,
+                               lv[i - 1].w, (uint8_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
     }
     // tiles are processed in slabs that keep planes + unit workspace bounded
-    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (3 * unit_ws_bytes(npx)), ((size_t)8 << 30) / (3 * npx * 2)));
+    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2)));
     std::vector<std::vector<uint8_t>> tile_blobs(total_tiles);
     for (int li = 0; li < nlev && rc == MIC_OK; li++) {
         const Level &L = lv[(size_t)li];
         const size_t ntl = (size_t)L.tx * L.ty;
         for (size_t t0 = 0; t0 < ntl && rc == MIC_OK; t0 += per) {
             const size_t nt = std::min(per, ntl - t0);
-            if ((rc = planes.reserve(nt * 3 * npx * 2 + 64))) break;
-            if ((rc = stats.reserve(nt * 3 * 8 + 64))) break;
-            std::vector<uint32_t> st(nt * 6);
-            for (size_t k = 0; k < nt * 3; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
+            if ((rc = planes.reserve(nt * P * npx * 2 + 64))) break;
+            if ((rc = stats.reserve(nt * P * 8 + 64))) break;
+            std::vector<uint32_t> st(nt * P * 2);
+            for (size_t k = 0; k < nt * P; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
             if (hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p, L.w, L.h,
-                               tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+            if (P == 3)
+                hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p, L.w, L.h,
+                                   tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+            else if (bits_per_sample == 16)
+                hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint16_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint16_t *)img[(size_t)li].p,
+                                   L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+            else
+                hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint8_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p,
+                                   L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
             if (hipGetLastError() != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
             if (hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
             if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
             // plane modes (compressWSIPlane, wsicompress.go:373-421)
             std::vector<mic_hip_unit> units; std::vector<size_t> unit_plane;
-            for (size_t p = 0; p < nt * 3; p++) {
+            for (size_t p = 0; p < nt * P; p++) {
                 const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
                 if (mn == mx) continue;                                                    // constant plane
                 units.push_back(mic_hip_unit{ p * npx, tile_w, tile_h, (uint16_t)std::max<uint32_t>(mx, 255u), 2 });   // :398-402
@@ -272,14 +353,14 @@ int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, 
                 packed.resize((size_t)offs.back() + 16);
                 if (offs.back() && hipMemcpy(packed.data(), d_blobs, (size_t)offs.back(), hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
             }
-            std::vector<long> unit_of(nt * 3, -1);
+            std::vector<long> unit_of(nt * P, -1);
             for (size_t k = 0; k < units.size(); k++) unit_of[unit_plane[k]] = (long)k;
             std::vector<uint16_t> rawbuf;
             for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
                 std::vector<uint8_t> &tb = tile_blobs[(size_t)L.first + t0 + k];
-                tb.assign(12, 0);
-                for (int p = 0; p < 3; p++) {
-                    const size_t pi = k * 3 + (size_t)p;
+                tb.assign(P == 3 ? 12 : 0, 0);                                             // RGB: three plane lengths, :341-363; grey: bare plane, :366-370
+                for (size_t p = 0; p < P; p++) {
+                    const size_t pi = k * P + p;
                     const size_t before = tb.size();
                     const uint32_t mn = st[2 * pi], mx = st[2 * pi + 1];
                     if (mn == mx) {
@@ -299,7 +380,7 @@ int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, 
                             tb.insert(tb.end(), rb, rb + npx * 2);
                         } else { rc = ustat; break; }
                     }
-                    put_u32(tb.data() + 4 * p, (uint32_t)(tb.size() - before));
+                    if (P == 3) put_u32(tb.data() + 4 * p, (uint32_t)(tb.size() - before));
                 }
             }
         }
@@ -312,7 +393,7 @@ int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, 
     memset(out, 0, hdr);                                                                    // WriteMIC3, wsiformat.go:99-165
     memcpy(out, "MIC3", 4); put_u32(out + 4, 1); put_u32(out + 8, (uint32_t)width); put_u32(out + 12, (uint32_t)height);
     put_u32(out + 16, (uint32_t)tile_w); put_u32(out + 20, (uint32_t)tile_h);
-    out[24] = 3; out[25] = 0; out[26] = 8; out[27] = 0x01 | 0x02;
+    out[24] = (uint8_t)channels; out[25] = 0; out[26] = (uint8_t)bits_per_sample; out[27] = (uint8_t)fmt.flags;
     out[28] = (uint8_t)nlev; out[29] = (uint8_t)(nlev >> 8);
     put_u64(out + 32, (uint64_t)total_tiles);
     for (int i = 0; i < nlev; i++) {
@@ -328,6 +409,20 @@ int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, 
         off += tile_blobs[t].size();
     }
     *out_len = hdr + total;
+    return MIC_OK;
+}
+
+int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
+                         uint8_t *out, size_t out_cap, size_t *out_len) {
+    return mic_hip_wsi_compress_ex(rgb, width, height, 3, 8, tile_w, tile_h, levels, out, out_cap, out_len);
+}
+
+// WSIHeader.Channels / BitsPerSample / ColorTransform (wsiformat.go:169-227)
+int mic_hip_wsi_format(const uint8_t *c, size_t len, int *channels, int *bits_per_sample, int *color_transform) {
+    if (!c) return MIC_ERR_ARGS;
+    Mic3 m; int rc = parse_mic3(c, len, m);
+    if (rc) return rc;
+    if (channels) *channels = m.channels; if (bits_per_sample) *bits_per_sample = m.bps; if (color_transform) *color_transform = (m.flags & 0x02) ? 1 : 0;
     return MIC_OK;
 }
 
@@ -361,7 +456,8 @@ int mic_hip_wsi_decompress_tile(const uint8_t *c, size_t len, int level, int til
     if (tile_x < 0 || tile_x >= L.tx || tile_y < 0 || tile_y >= L.ty) return MIC_ERR_ARGS;
     const int aw = std::min(m.tw, L.w - tile_x * m.tw), ah = std::min(m.th, L.h - tile_y * m.th);
     if (aw <= 0 || ah <= 0) return MIC_ERR_CORRUPT;
-    if ((size_t)aw * ah * 3 > out_cap) return MIC_ERR_CAPACITY;
+    if (!m.supported()) return MIC_ERR_UNSUPPORTED;
+    if ((size_t)aw * ah * m.bpp() > out_cap) return MIC_ERR_CAPACITY;
     if (out_w) *out_w = aw; if (out_h) *out_h = ah;
     std::lock_guard<std::mutex> lk(g_mu);
     if ((rc = ensure_device())) return rc;
@@ -377,7 +473,8 @@ int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_
     if (rc) return rc;
     if (level < 0 || level >= m.nlev) return MIC_ERR_ARGS;
     const Level &L = m.lv[(size_t)level];
-    if (L.w <= 0 || L.h <= 0 || (size_t)L.w * L.h * 3 > out_cap) return (L.w <= 0 || L.h <= 0) ? MIC_ERR_CORRUPT : MIC_ERR_CAPACITY;
+    if (!m.supported()) return MIC_ERR_UNSUPPORTED;
+    if (L.w <= 0 || L.h <= 0 || (size_t)L.w * L.h * m.bpp() > out_cap) return (L.w <= 0 || L.h <= 0) ? MIC_ERR_CORRUPT : MIC_ERR_CAPACITY;
     if ((size_t)L.tx * m.tw < (size_t)L.w || (size_t)L.ty * m.th < (size_t)L.h) return MIC_ERR_CORRUPT;
     std::vector<size_t> tiles; std::vector<int4> place;
     for (int ty = 0; ty < L.ty; ty++) for (int tx = 0; tx < L.tx; tx++) {
@@ -405,7 +502,9 @@ int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x
     if ((int64_t)x + w > L.w) w = L.w - x;                                                  // :232-237
     if ((int64_t)y + h > L.h) h = L.h - y;
     if (w <= 0 || h <= 0) return MIC_ERR_ARGS;                                              // "MIC3: empty region"
-    if ((size_t)w * h * 3 > out_cap) return MIC_ERR_CAPACITY;
+    if (!m.supported()) return MIC_ERR_UNSUPPORTED;
+    const size_t bpp = m.bpp();
+    if ((size_t)w * h * bpp > out_cap) return MIC_ERR_CAPACITY;
     const int tx0 = x / m.tw, ty0 = y / m.th, tx1 = (x + w - 1) / m.tw, ty1 = (y + h - 1) / m.th;
     const int bx = tx0 * m.tw, by = ty0 * m.th;
     const int bw = std::min((tx1 + 1) * m.tw, L.w) - bx, bh = std::min((ty1 + 1) * m.th, L.h) - by;
@@ -416,14 +515,14 @@ int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x
         tiles.push_back((size_t)L.first + (size_t)ty * L.tx + tx);
         place.push_back(make_int4(tx * m.tw - bx, ty * m.th - by, aw, ah));
     }
-    std::vector<uint8_t> box((size_t)bw * bh * 3);
+    std::vector<uint8_t> box((size_t)bw * bh * bpp);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if ((rc = ensure_device())) return rc;
         if ((rc = decode_tiles(c, len, m, tiles, place, box.data(), bw, bh))) return rc;
     }
     for (int r = 0; r < h; r++)
-        memcpy(rgb_out + (size_t)r * w * 3, box.data() + ((size_t)(y - by + r) * bw + (size_t)(x - bx)) * 3, (size_t)w * 3);
+        memcpy(rgb_out + (size_t)r * w * bpp, box.data() + ((size_t)(y - by + r) * bw + (size_t)(x - bx)) * bpp, (size_t)w * bpp);
     if (out_w) *out_w = w;
     if (out_h) *out_h = h;
     return MIC_OK;

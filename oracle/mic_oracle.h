@@ -118,6 +118,16 @@ int mico_wsi_decompress_tile(const uint8_t *in, size_t len, int tw, int th,
 int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h,
                       int levels /* 0 = auto */,
                       uint8_t *out, size_t cap, size_t *out_len);
+/* CompressWSI for 8-bit RGB (channels 3) or 8/16-bit greyscale (channels 1) */
+int mico_wsi_compress_ex(const uint8_t *px, int w, int h, int channels, int bps,
+                         int tile_w, int tile_h, int levels /* 0 = auto */,
+                         uint8_t *out, size_t cap, size_t *out_len);
+/* compressGreyTileBlob / decompressGreyTileBlob (wsicompress.go:366-370, :477-484) */
+int mico_wsi_compress_grey_tile(const uint8_t *px, int tw, int th, int bps,
+                                uint8_t *out, size_t cap, size_t *out_len);
+int mico_wsi_decompress_grey_tile(const uint8_t *in, size_t len, int tw, int th,
+                                  int bps, uint8_t *px);
+/* DecompressWSITile: cropped tile, bytes per pixel follow the header's channels / bits */
 int mico_wsi_decompress_tile_at(const uint8_t *in, size_t len, int level,
                                 int tx, int ty, uint8_t *rgb, size_t cap,
                                 int *tw, int *th);

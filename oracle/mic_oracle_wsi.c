@@ -1,11 +1,13 @@
 /*
- * mic_oracle_wsi.c -- CPU restatement of MIC's MIC3 / WSI path for 8-bit RGB.
+ * mic_oracle_wsi.c -- CPU restatement of MIC's MIC3 / WSI path: 8-bit RGB and 8/16-bit greyscale.
  * TEST INFRASTRUCTURE ONLY (see mic_oracle.h).
  *
  * YCoCg-R (asm_amd64.go:88-121, ycocgr.go:19-35), 2x2 box pyramid (wsipyramid.go:10-32),
  * zero-padded tiles (wsicompress.go:529-555), plane modes (wsicompress.go:373-421, :464-500),
  * tile blob (wsicompress.go:319-364, :430-462), MIC3 container (wsiformat.go:99-285),
  * CompressWSI (wsicompress.go:27-171), DecompressWSITile (:175-217).
+ * Greyscale: Downsample2xGrey (wsipyramid.go:34-55), compressGreyTileBlob / decompressGreyTileBlob
+ * (wsicompress.go:366-370, :477-484), bytesToUint16Slice / uint16ToBytes (:573-603).
  */
 #include "mic_oracle_int.h"
 
@@ -124,10 +126,40 @@ int mico_wsi_decompress_tile(const uint8_t *in, size_t len, int tw, int th, uint
     return rc;
 }
 
-/* CompressWSI for 8-bit RGB, wsicompress.go:27-171 + wsiformat.go:99-165, :244-285 */
-int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, int levels_req,
-                      uint8_t *out, size_t cap, size_t *out_len) {
-    if (!rgb || w <= 0 || h <= 0) return MICO_ERR_ARGS;
+/* bytesToUint16Slice / uint16ToBytes, wsicompress.go:573-603: one byte per sample up to 8 bits, else little-endian pairs */
+static uint16_t sample_get(const uint8_t *p, size_t i, int bps) { return bps <= 8 ? p[i] : (uint16_t)(p[2 * i] | (p[2 * i + 1] << 8)); }
+static void sample_put(uint8_t *p, size_t i, int bps, uint16_t v) { if (bps <= 8) p[i] = (uint8_t)v; else { p[2 * i] = (uint8_t)v; p[2 * i + 1] = (uint8_t)(v >> 8); } }
+
+/* compressGreyTileBlob, wsicompress.go:366-370: the tile blob is the plane blob itself (no length prefix) */
+int mico_wsi_compress_grey_tile(const uint8_t *px, int tw, int th, int bps, uint8_t *out, size_t cap, size_t *out_len) {
+    size_t n = (size_t)tw * (size_t)th;
+    uint16_t *pl = (uint16_t *)malloc(sizeof(uint16_t) * n);
+    if (!pl) return MICO_ERR_NOMEM;
+    for (size_t i = 0; i < n; i++) pl[i] = sample_get(px, i, bps);
+    int rc = compress_plane(pl, tw, th, out, cap, out_len);
+    free(pl);
+    return rc;
+}
+
+/* decompressGreyTileBlob, wsicompress.go:477-484 */
+int mico_wsi_decompress_grey_tile(const uint8_t *in, size_t len, int tw, int th, int bps, uint8_t *px) {
+    size_t n = (size_t)tw * (size_t)th;
+    uint16_t *pl = (uint16_t *)malloc(sizeof(uint16_t) * n);
+    if (!pl) return MICO_ERR_NOMEM;
+    int rc = decompress_plane(in, len, tw, th, pl);
+    if (rc == MICO_OK) for (size_t i = 0; i < n; i++) sample_put(px, i, bps, pl[i]);
+    free(pl);
+    return rc;
+}
+
+/* CompressWSI, wsicompress.go:27-171 + wsiformat.go:99-165, :244-285.  channels 3 / 8 bits takes the RGB tile blob,
+ * channels 1 (8 or 16 bits) the greyscale one (compressTileBlob, :312-317). */
+int mico_wsi_compress_ex(const uint8_t *px, int w, int h, int channels, int bps, int tile_w, int tile_h, int levels_req,
+                         uint8_t *out, size_t cap, size_t *out_len) {
+    if (!px || w <= 0 || h <= 0) return MICO_ERR_ARGS;
+    if (!((channels == 3 && bps == 8) || (channels == 1 && (bps == 8 || bps == 16)))) return MICO_ERR_ARGS;
+    const int grey = channels == 1;
+    const size_t bpp = (size_t)channels * (bps == 16 ? 2 : 1);          /* bytesPerPixel, wsicompress.go:530-533 */
     if (tile_w == 0) tile_w = 256;
     if (tile_h == 0) tile_h = 256;
     int num_levels = levels_req;
@@ -147,18 +179,26 @@ int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, 
     }
     uint8_t *pyr[32]; memset(pyr, 0, sizeof pyr);
     int pw[32], ph[32];
-    pyr[0] = (uint8_t *)rgb; pw[0] = w; ph[0] = h;
+    pyr[0] = (uint8_t *)px; pw[0] = w; ph[0] = h;
     int rc = MICO_OK;
-    for (int i = 1; i < num_levels; i++) {                              /* Downsample2xRGB, wsipyramid.go:10-32 */
+    for (int i = 1; i < num_levels; i++) {
         int nw = pw[i - 1] / 2, nh = ph[i - 1] / 2;
         if (nw == 0 || nh == 0) { num_levels = i; break; }
-        uint8_t *d = (uint8_t *)malloc((size_t)nw * nh * 3);
+        uint8_t *d = (uint8_t *)malloc((size_t)nw * nh * bpp);
         if (!d) { rc = MICO_ERR_NOMEM; num_levels = i; break; }
         const uint8_t *s = pyr[i - 1]; int sw = pw[i - 1];
-        for (int y = 0; y < nh; y++) for (int x = 0; x < nw; x++) for (int c = 0; c < 3; c++) {
-            int v = s[((size_t)(2 * y) * sw + 2 * x) * 3 + c] + s[((size_t)(2 * y) * sw + 2 * x + 1) * 3 + c] +
-                    s[((size_t)(2 * y + 1) * sw + 2 * x) * 3 + c] + s[((size_t)(2 * y + 1) * sw + 2 * x + 1) * 3 + c];
-            d[((size_t)y * nw + x) * 3 + c] = (uint8_t)((v + 2) / 4);
+        if (!grey) {                                                    /* Downsample2xRGB, wsipyramid.go:10-32 */
+            for (int y = 0; y < nh; y++) for (int x = 0; x < nw; x++) for (int c = 0; c < 3; c++) {
+                int v = s[((size_t)(2 * y) * sw + 2 * x) * 3 + c] + s[((size_t)(2 * y) * sw + 2 * x + 1) * 3 + c] +
+                        s[((size_t)(2 * y + 1) * sw + 2 * x) * 3 + c] + s[((size_t)(2 * y + 1) * sw + 2 * x + 1) * 3 + c];
+                d[((size_t)y * nw + x) * 3 + c] = (uint8_t)((v + 2) / 4);
+            }
+        } else {                                                        /* Downsample2xGrey on u16, wsipyramid.go:34-55 */
+            for (int y = 0; y < nh; y++) for (int x = 0; x < nw; x++) {
+                uint32_t v = (uint32_t)sample_get(s, (size_t)(2 * y) * sw + 2 * x, bps) + sample_get(s, (size_t)(2 * y) * sw + 2 * x + 1, bps) +
+                             sample_get(s, (size_t)(2 * y + 1) * sw + 2 * x, bps) + sample_get(s, (size_t)(2 * y + 1) * sw + 2 * x + 1, bps);
+                sample_put(d, (size_t)y * nw + x, bps, (uint16_t)((v + 2) / 4));
+            }
         }
         pyr[i] = d; pw[i] = nw; ph[i] = nh;
         lw[i] = nw; lh[i] = nh; ltx[i] = (nw + tile_w - 1) / tile_w; lty[i] = (nh + tile_h - 1) / tile_h;
@@ -166,14 +206,15 @@ int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, 
     size_t total_tiles = 0;
     for (int i = 0; i < num_levels; i++) { lfirst[i] = (int)total_tiles; total_tiles += (size_t)ltx[i] * lty[i]; }
     size_t hdr = 48 + 20 * (size_t)num_levels + 16 * total_tiles;
-    uint8_t *tile = (uint8_t *)malloc((size_t)tile_w * tile_h * 3);
+    uint8_t *tile = (uint8_t *)malloc((size_t)tile_w * tile_h * bpp);
     if (rc == MICO_OK && (!tile || cap < hdr)) rc = tile ? MICO_ERR_CAPACITY : MICO_ERR_NOMEM;
     size_t off = 0;
     if (rc == MICO_OK) {
         memset(out, 0, hdr);
         memcpy(out, "MIC3", 4); put32(out + 4, 1); put32(out + 8, (uint32_t)w); put32(out + 12, (uint32_t)h);
         put32(out + 16, (uint32_t)tile_w); put32(out + 20, (uint32_t)tile_h);
-        out[24] = 3; out[25] = 0; out[26] = 8; out[27] = 0x01 | 0x02;
+        out[24] = (uint8_t)channels; out[25] = 0; out[26] = (uint8_t)bps;
+        out[27] = (uint8_t)(0x01 | (grey ? 0 : 0x02));                  /* FlagSpatial | FlagColorTransform (RGB only, wsiformat.go:86-96) */
         out[28] = (uint8_t)num_levels; out[29] = (uint8_t)(num_levels >> 8);
         put64(out + 32, (uint64_t)total_tiles);
         for (int i = 0; i < num_levels; i++) {
@@ -183,14 +224,15 @@ int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, 
         size_t ti = 0;
         for (int lv = 0; lv < num_levels && rc == MICO_OK; lv++) {
             for (int ty = 0; ty < lty[lv] && rc == MICO_OK; ty++) for (int tx = 0; tx < ltx[lv] && rc == MICO_OK; tx++) {
-                memset(tile, 0, (size_t)tile_w * tile_h * 3);         /* extractTileRGB: zero padding */
+                memset(tile, 0, (size_t)tile_w * tile_h * bpp);       /* extractTileRGB: zero padding */
                 for (int yy = 0; yy < tile_h; yy++) {
                     int sy = ty * tile_h + yy; if (sy >= ph[lv]) break;
                     int sx = tx * tile_w; int cw = pw[lv] - sx; if (cw > tile_w) cw = tile_w;
-                    memcpy(tile + (size_t)yy * tile_w * 3, pyr[lv] + ((size_t)sy * pw[lv] + sx) * 3, (size_t)cw * 3);
+                    memcpy(tile + (size_t)yy * tile_w * bpp, pyr[lv] + ((size_t)sy * pw[lv] + sx) * bpp, (size_t)cw * bpp);
                 }
                 size_t bl = 0;
-                rc = mico_wsi_compress_tile(tile, tile_w, tile_h, out + hdr + off, cap - hdr - off, &bl);
+                rc = grey ? mico_wsi_compress_grey_tile(tile, tile_w, tile_h, bps, out + hdr + off, cap - hdr - off, &bl)
+                          : mico_wsi_compress_tile(tile, tile_w, tile_h, out + hdr + off, cap - hdr - off, &bl);
                 if (rc) break;
                 uint8_t *e = out + 48 + 20 * (size_t)num_levels + 16 * ti;
                 put64(e, (uint64_t)off); put64(e + 8, (uint64_t)bl);
@@ -204,6 +246,11 @@ int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, 
     return rc;
 }
 
+int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h, int levels_req,
+                      uint8_t *out, size_t cap, size_t *out_len) {
+    return mico_wsi_compress_ex(rgb, w, h, 3, 8, tile_w, tile_h, levels_req, out, cap, out_len);
+}
+
 /* DecompressWSITile, wsicompress.go:175-217 (crop to the level's edge) */
 int mico_wsi_decompress_tile_at(const uint8_t *in, size_t len, int level, int tx, int ty,
                                 uint8_t *rgb, size_t cap, int *tw_out, int *th_out) {
@@ -212,7 +259,9 @@ int mico_wsi_decompress_tile_at(const uint8_t *in, size_t len, int level, int tx
     int channels = in[24] | (in[25] << 8), bps = in[26];
     int nlev = in[28] | (in[29] << 8);
     uint64_t total = get64(in + 32);
-    if (channels != 3 || bps != 8 || !(in[27] & 0x02)) return MICO_ERR_ARGS;
+    const int grey = channels == 1 && (bps == 8 || bps == 16);
+    if (!grey && (channels != 3 || bps != 8 || !(in[27] & 0x02))) return MICO_ERR_ARGS;
+    const size_t bpp = (size_t)channels * (bps == 16 ? 2 : 1);
     if (len < 48 + 20 * (size_t)nlev || total > (len - 48 - 20 * (size_t)nlev) / 16) return MICO_ERR_CORRUPT;
     if (level < 0 || level >= nlev) return MICO_ERR_ARGS;
     const uint8_t *ld = in + 48 + 20 * (size_t)level;
@@ -224,16 +273,17 @@ int mico_wsi_decompress_tile_at(const uint8_t *in, size_t len, int level, int tx
     const uint8_t *e = in + 48 + 20 * (size_t)nlev + 16 * gi;
     uint64_t bo = get64(e), bl = get64(e + 8);
     if (data_off + bo + bl > len) return MICO_ERR_CORRUPT;
-    uint8_t *full = (uint8_t *)malloc((size_t)tile_w * tile_h * 3);
+    uint8_t *full = (uint8_t *)malloc((size_t)tile_w * tile_h * bpp);
     if (!full) return MICO_ERR_NOMEM;
-    int rc = mico_wsi_decompress_tile(in + data_off + bo, (size_t)bl, tile_w, tile_h, full);
+    int rc = grey ? mico_wsi_decompress_grey_tile(in + data_off + bo, (size_t)bl, tile_w, tile_h, bps, full)     /* decompressTileBlob, :424-429 */
+                  : mico_wsi_decompress_tile(in + data_off + bo, (size_t)bl, tile_w, tile_h, full);
     if (rc == MICO_OK) {
         int aw = tile_w, ah = tile_h;
         if (lw - tx * tile_w < aw) aw = lw - tx * tile_w;
         if (lh - ty * tile_h < ah) ah = lh - ty * tile_h;
         *tw_out = aw; *th_out = ah;
-        if ((size_t)aw * ah * 3 > cap) rc = MICO_ERR_CAPACITY;
-        else for (int y = 0; y < ah; y++) memcpy(rgb + (size_t)y * aw * 3, full + (size_t)y * tile_w * 3, (size_t)aw * 3);
+        if ((size_t)aw * ah * bpp > cap) rc = MICO_ERR_CAPACITY;
+        else for (int y = 0; y < ah; y++) memcpy(rgb + (size_t)y * aw * bpp, full + (size_t)y * tile_w * bpp, (size_t)aw * bpp);
     }
     free(full);
     return rc;

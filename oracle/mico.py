@@ -229,8 +229,29 @@ def wsi_compress(rgb: np.ndarray, tile_w: int = 256, tile_h: int = 256, levels: 
     return rc, (out[: n.value].tobytes() if rc == 0 else b"")
 
 
+def wsi_compress_grey(img: np.ndarray, tile_w: int = 256, tile_h: int = 256, levels: int = 0):
+    """CompressWSI with channels=1; uint8 -> 8 bits per sample, uint16 -> 16 (little-endian bytes)."""
+    bps = 16 if img.dtype == np.uint16 else 8
+    img = np.ascontiguousarray(img, dtype="<u2" if bps == 16 else np.uint8)
+    h, w = img.shape
+    out = np.empty(img.nbytes * 4 + (1 << 20), dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_wsi_compress_ex(_p(img), w, h, 1, bps, tile_w, tile_h, levels, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
 def wsi_decompress_tile_at(b: bytes, level: int, tx: int, ty: int, tile_w: int = 256, tile_h: int = 256):
     a = np.frombuffer(bytes(b), dtype=np.uint8)
+    channels, bps = int(a[24]) | (int(a[25]) << 8), int(a[26])
+    if channels == 1:
+        out = np.empty(tile_w * tile_h * (2 if bps == 16 else 1), dtype=np.uint8)
+        tw, th = C.c_int(), C.c_int()
+        rc = lib().mico_wsi_decompress_tile_at(_p(a), C.c_size_t(a.size), level, tx, ty, _p(out), C.c_size_t(out.size), C.byref(tw), C.byref(th))
+        if rc:
+            return rc, None
+        n = tw.value * th.value
+        px = out[: n * 2].view("<u2") if bps == 16 else out[:n]
+        return rc, px.reshape(th.value, tw.value).copy()
     out = np.empty(tile_w * tile_h * 3, dtype=np.uint8)
     tw, th = C.c_int(), C.c_int()
     rc = lib().mico_wsi_decompress_tile_at(_p(a), C.c_size_t(a.size), level, tx, ty, _p(out), C.c_size_t(out.size), C.byref(tw), C.byref(th))

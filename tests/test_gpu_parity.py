@@ -421,6 +421,56 @@ def test_wsi_region_matches_the_slide(mic, synth, gpu_ready):
         mic.decompress_wsi_region(blob, 5, 0, 0, 10, 10)
 
 
+@pytest.mark.parametrize("bits", [8, 16])
+def test_wsi_greyscale_matches_oracle(mic, mico, synth, gpu_ready, bits):
+    """CompressWSI with channels = 1 (wsicompress.go:58-69, :366-370): Downsample2xGrey pyramid, one plane per tile, bare plane blobs;
+    tile / level / region decode (decompressGreyTileBlob, :477-484) in the slide's sample width."""
+    from test_oracle_wavelet_wsi import _grey_slide
+    W, H = 600, 420
+    img = _grey_slide(synth, W, H, bits, seed=6)
+    rc, want = mico.wsi_compress_grey(img)
+    assert rc == 0
+    got = mic.compress_wsi(img, W, H, channels=1, bits_per_sample=bits)
+    assert got == want
+    hdr = mic.read_wsi_header(got)
+    assert (hdr["channels"], hdr["bits_per_sample"], hdr["color_transform"]) == (1, bits, False) and len(hdr["levels"]) == 3
+    lv0 = mic.decompress_wsi_level(got, 0)
+    assert lv0.dtype == img.dtype and np.array_equal(lv0, img)
+    for lvl, L in enumerate(hdr["levels"]):
+        for ty in range(L["tiles_y"]):
+            for tx in range(L["tiles_x"]):
+                rc, t = mico.wsi_decompress_tile_at(got, lvl, tx, ty)
+                assert rc == 0 and np.array_equal(mic.decompress_wsi_tile(got, lvl, tx, ty), t)
+    a = img.astype(np.uint32)
+    lv1 = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) // 4).astype(img.dtype)
+    assert np.array_equal(mic.decompress_wsi_level(got, 1), lv1)
+    assert np.array_equal(mic.decompress_wsi_region(got, 0, 200, 100, 300, 250), img[100:350, 200:500])
+    assert np.array_equal(mic.decompress_wsi_region(got, 1, 250, 200, 500, 500), lv1[200:, 250:])
+    # odd tile shape, explicit level count
+    rc, want = mico.wsi_compress_grey(img, 200, 100, 2)
+    assert rc == 0 and mic.compress_wsi(img, W, H, channels=1, bits_per_sample=bits, tile_w=200, tile_h=100, levels=2) == want
+
+
+def test_wsi_greyscale_noise_errors_and_raw_planes(mic, mico, synth, gpu_ready):
+    from test_oracle_wavelet_wsi import grey_raw_container
+    n16 = (synth.hash_u64(256 * 256, 31).reshape(256, 256) & np.uint64(0xFFFF)).astype(np.uint16)
+    n14 = n16 & np.uint16(0x3FFF)
+    rc, want = mico.wsi_compress_grey(n14)
+    assert rc == 0 and mic.compress_wsi(n14, 256, 256, channels=1, bits_per_sample=16) == want
+    assert np.array_equal(mic.decompress_wsi_level(want, 0), n14)
+    rc, _ = mico.wsi_compress_grey(n16)                        # the reference's normaliser gives up on 16-bit noise
+    with pytest.raises(mic.MicError) as e:
+        mic.compress_wsi(n16, 256, 256, channels=1, bits_per_sample=16)
+    assert rc != 0 and e.value.code == rc
+    for img in (n16[:40, :56], (n16[:40, :56] >> 8).astype(np.uint8)):    # planeRaw in a grey tile, wsicompress.go:515-523
+        blob = grey_raw_container(np.ascontiguousarray(img))
+        assert np.array_equal(mic.decompress_wsi_tile(blob, 0, 0, 0), img)
+        assert np.array_equal(mic.decompress_wsi_region(blob, 0, 5, 7, 20, 11), img[7:18, 5:25])
+    with pytest.raises(mic.MicError) as e:                     # RGB needs 8 bits (compressTileBlob would misread the bytes)
+        mic.compress_wsi(np.zeros((8, 8, 3), np.uint16), 8, 8, channels=3, bits_per_sample=16)
+    assert e.value.code == mic.MIC_ERR_UNSUPPORTED
+
+
 def test_wsi_white_slide_is_101_bytes(mic, gpu_ready):
     white = np.full((256, 256, 3), 255, dtype=np.uint8)
     blob = mic.compress_wsi(white, 256, 256)

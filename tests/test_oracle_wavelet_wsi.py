@@ -134,3 +134,75 @@ def test_wsi_noise_plane_falls_back_to_raw(mico, synth):
     assert rc == 0
     rc, back = mico.wsi_decompress_tile(blob, 256, 256)
     assert rc == 0 and np.array_equal(back, noise)
+
+
+# ---- greyscale slides: CompressWSI with channels = 1 (wsicompress.go:58-69, :366-370, :477-484) ----
+def _grey_slide(synth, w, h, bits, seed):
+    rgb = synth.wsi_like(w, h, seed=seed).astype(np.uint32)
+    lum = (rgb[:, :, 0] * 2 + rgb[:, :, 1] * 5 + rgb[:, :, 2]) // 8          # 0..255
+    if bits == 8:
+        return lum.astype(np.uint8)
+    noise = (synth.hash_u64(w * h, seed + 1).reshape(h, w) & np.uint64(0xF)).astype(np.uint32)
+    return (lum * 257 // 16 + noise).astype(np.uint16)                         # 12-bit range in 16-bit samples
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_wsi_greyscale_container_and_pyramid(mico, synth, bits):
+    img = _grey_slide(synth, 600, 420, bits, seed=6)
+    rc, mic3 = mico.wsi_compress_grey(img)
+    assert rc == 0
+    assert mic3[:4] == b"MIC3" and mic3[24] == 1 and mic3[26] == bits and mic3[27] == 0x01     # FlagSpatial only
+    assert int.from_bytes(mic3[28:30], "little") == 3
+    out = np.zeros_like(img)
+    for ty in range(2):
+        for tx in range(3):
+            rc, t = mico.wsi_decompress_tile_at(mic3, 0, tx, ty)
+            assert rc == 0 and t.dtype == img.dtype
+            out[ty * 256: ty * 256 + t.shape[0], tx * 256: tx * 256 + t.shape[1]] = t
+    assert np.array_equal(out, img)
+    a = img.astype(np.uint32)                                                   # Downsample2xGrey, wsipyramid.go:34-55
+    want = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) // 4).astype(img.dtype)
+    rc, t = mico.wsi_decompress_tile_at(mic3, 1, 0, 0)
+    assert rc == 0 and np.array_equal(t, want[:256, :256])
+    # a grey tile blob is the bare plane blob: constant 1000 -> {planeConstant, lo, hi}; the 4x4 -> 2x2 case of wsi_test.go:272-285
+    flat = np.full((4, 4), 1000, np.uint16)
+    rc, small = mico.wsi_compress_grey(flat, 2, 2, 2)
+    assert rc == 0
+    data_off = 48 + 20 * 2 + 16 * 5
+    assert small[data_off:] == bytes([1, 0xE8, 0x03]) * 5
+    rc, t = mico.wsi_decompress_tile_at(small, 1, 0, 0, 2, 2)
+    assert rc == 0 and np.array_equal(t, np.full((2, 2), 1000, np.uint16))
+
+
+def grey_raw_container(img: np.ndarray) -> bytes:
+    """A one-tile greyscale MIC3 whose plane is stored raw (planeRaw, wsicompress.go:403-414, :515-523), built by hand:
+    the encoder only takes that branch on ErrIncompressible, which a single 16-bit plane practically never returns."""
+    h, w = img.shape
+    bits = 16 if img.dtype == np.uint16 else 8
+    hdr = bytearray(48)
+    hdr[0:4] = b"MIC3"
+    hdr[4:8] = (1).to_bytes(4, "little")
+    for k, v in enumerate((w, h, w, h)):
+        hdr[8 + 4 * k: 12 + 4 * k] = v.to_bytes(4, "little")
+    hdr[24], hdr[26], hdr[27], hdr[28] = 1, bits, 0x01, 1
+    hdr[32:40] = (1).to_bytes(8, "little")
+    level = b"".join(v.to_bytes(4, "little") for v in (w, h, 1, 1, 0))
+    blob = bytes([3]) + img.astype("<u2").tobytes()
+    entry = (0).to_bytes(8, "little") + len(blob).to_bytes(8, "little")
+    return bytes(hdr) + level + entry + blob
+
+
+def test_wsi_greyscale_noise(mico, synth):
+    # 14-bit noise still codes (2 tokens per pixel, body < 2 bytes per token); 16-bit noise makes the reference's normaliser
+    # fail outright, which CompressWSI passes on as an error (wsicompress.go:415)
+    n14 = (synth.hash_u64(256 * 256, 31).reshape(256, 256) & np.uint64(0x3FFF)).astype(np.uint16)
+    rc, mic3 = mico.wsi_compress_grey(n14)
+    assert rc == 0 and mic3[48 + 20 + 16] == 2
+    rc, t = mico.wsi_decompress_tile_at(mic3, 0, 0, 0)
+    assert rc == 0 and np.array_equal(t, n14)
+    n16 = (synth.hash_u64(256 * 256, 31).reshape(256, 256) & np.uint64(0xFFFF)).astype(np.uint16)
+    rc, _ = mico.wsi_compress_grey(n16)
+    assert rc == -8
+    for img in (n16[:40, :56], (n16[:40, :56] >> 8).astype(np.uint8)):
+        rc, t = mico.wsi_decompress_tile_at(grey_raw_container(img), 0, 0, 0, 56, 40)
+        assert rc == 0 and np.array_equal(t, img)
