@@ -194,6 +194,23 @@ int mic_hip_wsi_decompress_region(const uint8_t *compressed, size_t compressed_l
                                   int x, int y, int w, int h,
                                   uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h);
 
+/* ---- single-frame RGB and the CLI's single-frame files ------------------------------------------ */
+/* Replaces CompressRGB / DecompressRGB (rgbcompress.go:25-33): YCoCg-R, then the three planes as in a WSI tile blob
+ * ([Y_len][Co_len][Cg_len] u32 LE + plane blobs); width and height travel out of band, as in the reference. */
+int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_rgb_decompress(const uint8_t *compressed, size_t compressed_len, int width, int height,
+                           uint8_t *rgb_out, size_t out_cap);
+/* MICR file (writeMICRFile, cmd/mic-compress/main.go:62-91): "MICR", width, height, CompressRGB blob. */
+int mic_hip_micr_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_micr_info(const uint8_t *compressed, size_t compressed_len, int *width, int *height);
+int mic_hip_micr_decompress(const uint8_t *compressed, size_t compressed_len, uint8_t *rgb_out, size_t out_cap);
+/* MIC1 file (writeMicFile, cmd/mic-compress/main.go:26-59): "MIC1", width, height, pipeline = 1, payload length,
+ * CompressSingleFrame{,4State,8State} stream (nstates = 2, 4 or 8; the decoder auto-detects). */
+int mic_hip_mic1_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int nstates,
+                          uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_mic1_info(const uint8_t *compressed, size_t compressed_len, int *width, int *height);
+int mic_hip_mic1_decompress(const uint8_t *compressed, size_t compressed_len, uint16_t *pixels_out, size_t out_cap_px);
+
 /* ---- device-resident sessions (inputs and outputs stay in HBM) ------------------------------ */
 /* A session owns the workspace for up to max_units units of up to max_px pixels each and
  * runs the same kernels as the calls above on data that is already on the device.  This is

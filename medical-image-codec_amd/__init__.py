@@ -89,6 +89,8 @@ ABI_SYMBOLS = [
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
+    "mic_hip_rgb_compress", "mic_hip_rgb_decompress", "mic_hip_micr_compress", "mic_hip_micr_info", "mic_hip_micr_decompress",
+    "mic_hip_mic1_compress", "mic_hip_mic1_info", "mic_hip_mic1_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
     "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
@@ -138,6 +140,14 @@ def lib() -> C.CDLL:
     L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_rgb_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_rgb_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.mic_hip_micr_compress.argtypes = L.mic_hip_rgb_compress.argtypes
+    L.mic_hip_micr_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mic_hip_micr_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.mic_hip_mic1_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_mic1_info.argtypes = L.mic_hip_micr_info.argtypes
+    L.mic_hip_mic1_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress_ex.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_wsi_format.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 3
     L.mic_hip_wsi_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.c_uint64)]
@@ -451,6 +461,68 @@ def decompress_wsi_level(compressed, level: int = 0) -> np.ndarray:
     if rc:
         _raise(rc, "decompress_wsi_level")
     return _wsi_shape(hdr, out, lv["width"], lv["height"])
+
+
+# ------------------------------------------------------------------ single-frame RGB, MIC1 / MICR files
+def compress_rgb(rgb, width: int, height: int, container: bool = False) -> bytes:
+    """CompressRGB (rgbcompress.go:25); container=True wraps it as a MICR file (cmd/mic-compress/main.go:62-91)."""
+    px = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1)
+    if px.size != width * height * 3:
+        raise MicError(MIC_ERR_ARGS, "compress_rgb")
+    cap = px.size * 4 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    fn = lib().mic_hip_micr_compress if container else lib().mic_hip_rgb_compress
+    rc = fn(px.ctypes.data, width, height, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_rgb")
+    return out[: n.value].tobytes()
+
+
+def decompress_rgb(compressed, width: int = 0, height: int = 0) -> np.ndarray:
+    """DecompressRGB (rgbcompress.go:31) when width / height are given, else a MICR file: (h, w, 3) uint8."""
+    c = _bytes_arr(compressed)
+    if width and height:
+        out = np.empty(width * height * 3, dtype=np.uint8)
+        rc = lib().mic_hip_rgb_decompress(c.ctypes.data, c.size, width, height, out.ctypes.data, out.size)
+    else:
+        w, h = C.c_int(), C.c_int()
+        rc = lib().mic_hip_micr_info(c.ctypes.data, c.size, C.byref(w), C.byref(h))
+        if rc:
+            _raise(rc, "decompress_rgb")
+        width, height = w.value, h.value
+        out = np.empty(width * height * 3, dtype=np.uint8)
+        rc = lib().mic_hip_micr_decompress(c.ctypes.data, c.size, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "decompress_rgb")
+    return out.reshape(height, width, 3)
+
+
+def write_mic1(pixels, width: int, height: int, max_value: int, nstates: int = 2) -> bytes:
+    """The CLI's single-frame .mic file (writeMicFile, cmd/mic-compress/main.go:26-59)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
+    if px.size != width * height:
+        raise MicError(MIC_ERR_ARGS, "write_mic1")
+    cap = px.size * 2 + 8192
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_mic1_compress(px.ctypes.data, width, height, max_value, nstates, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "write_mic1")
+    return out[: n.value].tobytes()
+
+
+def read_mic1(compressed) -> np.ndarray:
+    c = _bytes_arr(compressed)
+    w, h = C.c_int(), C.c_int()
+    rc = lib().mic_hip_mic1_info(c.ctypes.data, c.size, C.byref(w), C.byref(h))
+    if rc:
+        _raise(rc, "read_mic1")
+    out = np.empty(w.value * h.value, dtype=np.uint16)
+    rc = lib().mic_hip_mic1_decompress(c.ctypes.data, c.size, out.ctypes.data, out.size)
+    if rc:
+        _raise(rc, "read_mic1")
+    return out.reshape(h.value, w.value)
 
 
 # ------------------------------------------------------------------ device-resident sessions

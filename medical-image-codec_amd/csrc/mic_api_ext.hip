@@ -183,7 +183,8 @@ int parse_mic3(const uint8_t *c, size_t len, Mic3 &m) {                       //
 
 // decode the given tiles (global indices) of one level into dst (an image of dst_w x dst_h pixels of the slide's format);
 // place[k] = where tile k goes and how much of it is kept
-int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<size_t> &tiles, const std::vector<int4> &place,
+struct TileBlob { const uint8_t *p; size_t len; };
+int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::vector<int4> &place,
                  uint8_t *rgb_out, int dst_w, int dst_h) {
     if (!m.supported()) return MIC_ERR_UNSUPPORTED;
     mic_hip_session *s = &g_default;
@@ -204,12 +205,7 @@ int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<
         struct Fill { size_t plane; int mode; uint16_t val; const uint8_t *raw; };
         std::vector<Fill> fills;
         for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
-            const size_t gi = tiles[t0 + k];
-            if (gi >= m.total) { rc = MIC_ERR_CORRUPT; break; }
-            const uint8_t *e = c + 48 + 20 * (size_t)m.nlev + 16 * gi;
-            const uint64_t bo = get_u64(e), bl = get_u64(e + 8);
-            if (m.data_off + bo + bl > len) { rc = MIC_ERR_CORRUPT; break; }              // ExtractTileBlob, wsiformat.go:230-241
-            const uint8_t *blob = c + m.data_off + bo;
+            const uint8_t *blob = tiles[t0 + k].p; const size_t bl = tiles[t0 + k].len;
             size_t pl_off[3] = { 0, 0, 0 }, pl_len[3] = { (size_t)bl, 0, 0 };              // greyscale: the blob is the plane, :477-484
             if (P == 3) {
                 if (bl < 12) { rc = MIC_ERR_CORRUPT; break; }
@@ -267,6 +263,101 @@ int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<
     return rc;
 }
 
+// the given tiles (global indices) of a MIC3 container: ExtractTileBlob (wsiformat.go:230-241), then decode_blobs
+int decode_tiles(const uint8_t *c, size_t len, const Mic3 &m, const std::vector<size_t> &tiles, const std::vector<int4> &place,
+                 uint8_t *rgb_out, int dst_w, int dst_h) {
+    std::vector<TileBlob> blobs;
+    for (size_t gi : tiles) {
+        if (gi >= m.total) return MIC_ERR_CORRUPT;
+        const uint8_t *e = c + 48 + 20 * (size_t)m.nlev + 16 * gi;
+        const uint64_t bo = get_u64(e), bl = get_u64(e + 8);
+        if (bo > len || bl > len || m.data_off + bo + bl > len) return MIC_ERR_CORRUPT;
+        blobs.push_back(TileBlob{ c + m.data_off + bo, (size_t)bl });
+    }
+    return decode_blobs(m, blobs, place, rgb_out, dst_w, dst_h);
+}
+
+// every tile of one pyramid level (image d_img on the device): extraction + transform + plane statistics, the unit codec over all
+// non-constant planes in slabs that keep planes + unit workspace bounded, then the tile blobs (compressTileBlob, wsicompress.go:312-370)
+int compress_level_tiles(mic_hip_session *s, const void *d_img, const Level &L, int tile_w, int tile_h, const Mic3 &fmt,
+                         std::vector<uint8_t> *blobs_out) {
+    const size_t P = (size_t)fmt.planes();
+    const size_t npx = (size_t)tile_w * tile_h;
+    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2)));
+    DevBuf planes, stats;
+    int rc = MIC_OK;
+    const size_t ntl = (size_t)L.tx * L.ty;
+    for (size_t t0 = 0; t0 < ntl && rc == MIC_OK; t0 += per) {
+        const size_t nt = std::min(per, ntl - t0);
+        if ((rc = planes.reserve(nt * P * npx * 2 + 64))) break;
+        if ((rc = stats.reserve(nt * P * 8 + 64))) break;
+        std::vector<uint32_t> st(nt * P * 2);
+        for (size_t k = 0; k < nt * P; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
+        if (hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+        if (P == 3)
+            hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img, L.w, L.h,
+                               tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        else if (fmt.bps == 16)
+            hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint16_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint16_t *)d_img,
+                               L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        else
+            hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint8_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img,
+                               L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        if (hipGetLastError() != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+        if (hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+        if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+        // plane modes (compressWSIPlane, wsicompress.go:373-421)
+        std::vector<mic_hip_unit> units; std::vector<size_t> unit_plane;
+        for (size_t p = 0; p < nt * P; p++) {
+            const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
+            if (mn == mx) continue;                                                    // constant plane
+            units.push_back(mic_hip_unit{ p * npx, tile_w, tile_h, (uint16_t)std::max<uint32_t>(mx, 255u), 2 });   // :398-402
+            unit_plane.push_back(p);
+        }
+        std::vector<uint64_t> offs(units.size() + 1, 0); std::vector<int32_t> ust(units.size()), uns(units.size());
+        std::vector<uint8_t> packed;
+        if (!units.empty()) {
+            if ((rc = session_encode_enqueue(s, (const uint16_t *)planes.p, units.data(), (int)units.size()))) break;
+            const uint8_t *d_blobs = nullptr;
+            if ((rc = session_encode_finish(s, &d_blobs, offs.data(), ust.data(), uns.data()))) break;
+            packed.resize((size_t)offs.back() + 16);
+            if (offs.back() && hipMemcpy(packed.data(), d_blobs, (size_t)offs.back(), hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+        }
+        std::vector<long> unit_of(nt * P, -1);
+        for (size_t k = 0; k < units.size(); k++) unit_of[unit_plane[k]] = (long)k;
+        std::vector<uint16_t> rawbuf;
+        for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
+            std::vector<uint8_t> &tb = blobs_out[t0 + k];
+            tb.assign(P == 3 ? 12 : 0, 0);                                             // RGB: three plane lengths, :341-363; grey: bare plane, :366-370
+            for (size_t p = 0; p < P; p++) {
+                const size_t pi = k * P + p;
+                const size_t before = tb.size();
+                const uint32_t mn = st[2 * pi], mx = st[2 * pi + 1];
+                if (mn == mx) {
+                    if (mn == 0) tb.push_back(0);                                      // planeConstantZero
+                    else { tb.push_back(1); tb.push_back((uint8_t)mn); tb.push_back((uint8_t)(mn >> 8)); }
+                } else {
+                    const long ui = unit_of[pi];
+                    const int32_t ustat = ust[(size_t)ui];
+                    if (ustat == MIC_OK) {
+                        tb.push_back(2);
+                        tb.insert(tb.end(), packed.begin() + (long)offs[(size_t)ui], packed.begin() + (long)offs[(size_t)ui + 1]);
+                    } else if (ustat == MIC_ERR_USE_RLE || ustat == MIC_ERR_INCOMPRESSIBLE) {      // raw fallback, :403-414
+                        rawbuf.resize(npx);
+                        if (hipMemcpy(rawbuf.data(), (uint16_t *)planes.p + pi * npx, npx * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
+                        tb.push_back(3);
+                        const uint8_t *rb = (const uint8_t *)rawbuf.data();
+                        tb.insert(tb.end(), rb, rb + npx * 2);
+                    } else { rc = ustat; break; }
+                }
+                if (P == 3) put_u32(tb.data() + 4 * p, (uint32_t)(tb.size() - before));
+            }
+        }
+    }
+    planes.release(); stats.release();
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,8 +386,7 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
     const size_t npx = (size_t)tile_w * tile_h;
     // pyramid on the device
     std::vector<DevBuf> img((size_t)nlev);
-    DevBuf planes, stats;
-    auto cleanup = [&]() { for (auto &b : img) b.release(); planes.release(); stats.release(); };
+    auto cleanup = [&]() { for (auto &b : img) b.release(); };
     if ((rc = img[0].reserve((size_t)width * height * bpp + 64))) { cleanup(); return rc; }
     if (hipMemcpyAsync(img[0].p, rgb, (size_t)width * height * bpp, hipMemcpyHostToDevice, s->stream) != hipSuccess) { cleanup(); return MIC_ERR_DEVICE; }
     for (int i = 1; i < nlev; i++) {
@@ -311,80 +401,9 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
             hipLaunchKernelGGL(k_wsi_downsample_grey<uint8_t>, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)i - 1].p,
                                lv[i - 1].w, (uint8_t *)img[(size_t)i].p, lv[i].w, lv[i].h);
     }
-    // tiles are processed in slabs that keep planes + unit workspace bounded
-    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2)));
     std::vector<std::vector<uint8_t>> tile_blobs(total_tiles);
-    for (int li = 0; li < nlev && rc == MIC_OK; li++) {
-        const Level &L = lv[(size_t)li];
-        const size_t ntl = (size_t)L.tx * L.ty;
-        for (size_t t0 = 0; t0 < ntl && rc == MIC_OK; t0 += per) {
-            const size_t nt = std::min(per, ntl - t0);
-            if ((rc = planes.reserve(nt * P * npx * 2 + 64))) break;
-            if ((rc = stats.reserve(nt * P * 8 + 64))) break;
-            std::vector<uint32_t> st(nt * P * 2);
-            for (size_t k = 0; k < nt * P; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
-            if (hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            if (P == 3)
-                hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p, L.w, L.h,
-                                   tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
-            else if (bits_per_sample == 16)
-                hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint16_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint16_t *)img[(size_t)li].p,
-                                   L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
-            else
-                hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint8_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)img[(size_t)li].p,
-                                   L.w, L.h, tile_w, tile_h, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
-            if (hipGetLastError() != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            if (hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            // plane modes (compressWSIPlane, wsicompress.go:373-421)
-            std::vector<mic_hip_unit> units; std::vector<size_t> unit_plane;
-            for (size_t p = 0; p < nt * P; p++) {
-                const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
-                if (mn == mx) continue;                                                    // constant plane
-                units.push_back(mic_hip_unit{ p * npx, tile_w, tile_h, (uint16_t)std::max<uint32_t>(mx, 255u), 2 });   // :398-402
-                unit_plane.push_back(p);
-            }
-            std::vector<uint64_t> offs(units.size() + 1, 0); std::vector<int32_t> ust(units.size()), uns(units.size());
-            std::vector<uint8_t> packed;
-            if (!units.empty()) {
-                if ((rc = session_encode_enqueue(s, (const uint16_t *)planes.p, units.data(), (int)units.size()))) break;
-                const uint8_t *d_blobs = nullptr;
-                if ((rc = session_encode_finish(s, &d_blobs, offs.data(), ust.data(), uns.data()))) break;
-                packed.resize((size_t)offs.back() + 16);
-                if (offs.back() && hipMemcpy(packed.data(), d_blobs, (size_t)offs.back(), hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-            }
-            std::vector<long> unit_of(nt * P, -1);
-            for (size_t k = 0; k < units.size(); k++) unit_of[unit_plane[k]] = (long)k;
-            std::vector<uint16_t> rawbuf;
-            for (size_t k = 0; k < nt && rc == MIC_OK; k++) {
-                std::vector<uint8_t> &tb = tile_blobs[(size_t)L.first + t0 + k];
-                tb.assign(P == 3 ? 12 : 0, 0);                                             // RGB: three plane lengths, :341-363; grey: bare plane, :366-370
-                for (size_t p = 0; p < P; p++) {
-                    const size_t pi = k * P + p;
-                    const size_t before = tb.size();
-                    const uint32_t mn = st[2 * pi], mx = st[2 * pi + 1];
-                    if (mn == mx) {
-                        if (mn == 0) tb.push_back(0);                                      // planeConstantZero
-                        else { tb.push_back(1); tb.push_back((uint8_t)mn); tb.push_back((uint8_t)(mn >> 8)); }
-                    } else {
-                        const long ui = unit_of[pi];
-                        const int32_t ustat = ust[(size_t)ui];
-                        if (ustat == MIC_OK) {
-                            tb.push_back(2);
-                            tb.insert(tb.end(), packed.begin() + (long)offs[(size_t)ui], packed.begin() + (long)offs[(size_t)ui + 1]);
-                        } else if (ustat == MIC_ERR_USE_RLE || ustat == MIC_ERR_INCOMPRESSIBLE) {      // raw fallback, :403-414
-                            rawbuf.resize(npx);
-                            if (hipMemcpy(rawbuf.data(), (uint16_t *)planes.p + pi * npx, npx * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = MIC_ERR_DEVICE; break; }
-                            tb.push_back(3);
-                            const uint8_t *rb = (const uint8_t *)rawbuf.data();
-                            tb.insert(tb.end(), rb, rb + npx * 2);
-                        } else { rc = ustat; break; }
-                    }
-                    if (P == 3) put_u32(tb.data() + 4 * p, (uint32_t)(tb.size() - before));
-                }
-            }
-        }
-    }
+    for (int li = 0; li < nlev && rc == MIC_OK; li++)
+        rc = compress_level_tiles(s, img[(size_t)li].p, lv[(size_t)li], tile_w, tile_h, fmt, tile_blobs.data() + lv[(size_t)li].first);
     cleanup();
     if (rc) return rc;
     size_t total = 0;
@@ -410,6 +429,97 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
     }
     *out_len = hdr + total;
     return MIC_OK;
+}
+
+// CompressRGB (rgbcompress.go:25-27) = compressRGBTileBlob on the whole image: one "tile" of width x height
+int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!rgb || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
+    if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
+    Mic3 fmt; fmt.channels = 3; fmt.bps = 8; fmt.flags = 0x03;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if ((rc = s->ensure(1, (size_t)width * height))) return rc;
+    DevBuf img;
+    if ((rc = img.reserve((size_t)width * height * 3 + 64))) return rc;
+    if (hipMemcpyAsync(img.p, rgb, (size_t)width * height * 3, hipMemcpyHostToDevice, s->stream) != hipSuccess) { img.release(); return MIC_ERR_DEVICE; }
+    std::vector<uint8_t> blob;
+    rc = compress_level_tiles(s, img.p, Level{ width, height, 1, 1, 0 }, width, height, fmt, &blob);
+    img.release();
+    if (rc) return rc;
+    if (blob.size() > out_cap) return MIC_ERR_CAPACITY;
+    memcpy(out, blob.data(), blob.size());
+    *out_len = blob.size();
+    return MIC_OK;
+}
+
+// DecompressRGB (rgbcompress.go:31-33)
+int mic_hip_rgb_decompress(const uint8_t *c, size_t len, int width, int height, uint8_t *rgb_out, size_t out_cap) {
+    if (!c || !rgb_out || width <= 0 || height <= 0) return MIC_ERR_ARGS;
+    if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
+    if ((size_t)width * height * 3 > out_cap) return MIC_ERR_CAPACITY;
+    Mic3 m; m.w = width; m.h = height; m.tw = width; m.th = height; m.channels = 3; m.bps = 8; m.flags = 0x03; m.nlev = 1; m.total = 1; m.data_off = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    return decode_blobs(m, std::vector<TileBlob>(1, TileBlob{ c, len }), std::vector<int4>(1, make_int4(0, 0, width, height)), rgb_out, width, height);
+}
+
+// MICR file = "MICR", width, height (u32 LE), CompressRGB blob (writeMICRFile, cmd/mic-compress/main.go:62-91)
+int mic_hip_micr_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!out || !out_len) return MIC_ERR_ARGS;
+    if (out_cap < 12) return MIC_ERR_CAPACITY;
+    size_t n = 0;
+    const int rc = mic_hip_rgb_compress(rgb, width, height, out + 12, out_cap - 12, &n);
+    if (rc) return rc;
+    memcpy(out, "MICR", 4); put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height);
+    *out_len = 12 + n;
+    return MIC_OK;
+}
+int mic_hip_micr_info(const uint8_t *c, size_t len, int *width, int *height) {
+    if (!c) return MIC_ERR_ARGS;
+    if (len < 12 || memcmp(c, "MICR", 4) != 0) return MIC_ERR_CORRUPT;
+    const uint32_t w = get_u32(c + 4), h = get_u32(c + 8);
+    if (w == 0 || h == 0 || w > (1u << 26) || h > (1u << 26)) return MIC_ERR_CORRUPT;
+    if (width) *width = (int)w; if (height) *height = (int)h;
+    return MIC_OK;
+}
+int mic_hip_micr_decompress(const uint8_t *c, size_t len, uint8_t *rgb_out, size_t out_cap) {
+    int w = 0, h = 0;
+    const int rc = mic_hip_micr_info(c, len, &w, &h);
+    if (rc) return rc;
+    return mic_hip_rgb_decompress(c + 12, len - 12, w, h, rgb_out, out_cap);
+}
+
+// MIC1 file = "MIC1", width, height, pipeline 1, payload length (u32 LE each), CompressSingleFrame stream
+// (writeMicFile, cmd/mic-compress/main.go:26-59; the stream's own magic tells the state count)
+int mic_hip_mic1_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int n_states,
+                          uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!out || !out_len) return MIC_ERR_ARGS;
+    if (out_cap < 20) return MIC_ERR_CAPACITY;
+    size_t n = 0;
+    const int rc = mic_hip_compress_frame(pixels, width, height, max_value, n_states, out + 20, out_cap - 20, &n);
+    if (rc) return rc;
+    if (n > 0xFFFFFFFFu) return MIC_ERR_UNSUPPORTED;
+    memcpy(out, "MIC1", 4); put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height); put_u32(out + 12, 1); put_u32(out + 16, (uint32_t)n);
+    *out_len = 20 + n;
+    return MIC_OK;
+}
+int mic_hip_mic1_info(const uint8_t *c, size_t len, int *width, int *height) {
+    if (!c) return MIC_ERR_ARGS;
+    if (len < 20 || memcmp(c, "MIC1", 4) != 0) return MIC_ERR_CORRUPT;
+    const uint32_t w = get_u32(c + 4), h = get_u32(c + 8);
+    if (w == 0 || h == 0 || w > (1u << 26) || h > (1u << 26) || get_u32(c + 12) != 1 || (size_t)get_u32(c + 16) > len - 20) return MIC_ERR_CORRUPT;
+    if (width) *width = (int)w; if (height) *height = (int)h;
+    return MIC_OK;
+}
+int mic_hip_mic1_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) {
+    int w = 0, h = 0;
+    const int rc = mic_hip_mic1_info(c, len, &w, &h);
+    if (rc) return rc;
+    if ((size_t)w * h > out_cap_px) return MIC_ERR_CAPACITY;
+    return mic_hip_decompress_frame(c + 20, get_u32(c + 16), pixels_out, w, h);
 }
 
 int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,

@@ -118,6 +118,13 @@ int mico_wsi_decompress_tile(const uint8_t *in, size_t len, int tw, int th,
 int mico_wsi_compress(const uint8_t *rgb, int w, int h, int tile_w, int tile_h,
                       int levels /* 0 = auto */,
                       uint8_t *out, size_t cap, size_t *out_len);
+/* single-frame files of cmd/mic-compress (main.go:26-91): MICR = header + CompressRGB blob (rgbcompress.go:25-33,
+ * which is mico_wsi_compress_tile on the whole image), MIC1 = header + CompressSingleFrame stream */
+int mico_micr_write(const uint8_t *rgb, int w, int h, uint8_t *out, size_t cap, size_t *out_len);
+int mico_micr_read(const uint8_t *in, size_t len, uint8_t *rgb, size_t cap, int *w, int *h);
+int mico_mic1_write(const uint16_t *px, int w, int h, uint16_t max_value, int nstates,
+                    uint8_t *out, size_t cap, size_t *out_len);
+int mico_mic1_read(const uint8_t *in, size_t len, uint16_t *px, size_t cap_px, int *w, int *h);
 /* CompressWSI for 8-bit RGB (channels 3) or 8/16-bit greyscale (channels 1) */
 int mico_wsi_compress_ex(const uint8_t *px, int w, int h, int channels, int bps,
                          int tile_w, int tile_h, int levels /* 0 = auto */,

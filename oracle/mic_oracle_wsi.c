@@ -126,6 +126,43 @@ int mico_wsi_decompress_tile(const uint8_t *in, size_t len, int tw, int th, uint
     return rc;
 }
 
+/* The CLI's single-frame files.  MICR (writeMICRFile, cmd/mic-compress/main.go:62-91): "MICR", width, height, CompressRGB blob
+ * (rgbcompress.go:25-27 = compressRGBTileBlob on the whole image).  MIC1 (writeMicFile, main.go:26-59): "MIC1", width, height,
+ * pipeline 1, payload length, CompressSingleFrame stream. */
+int mico_micr_write(const uint8_t *rgb, int w, int h, uint8_t *out, size_t cap, size_t *out_len) {
+    if (cap < 12) return MICO_ERR_CAPACITY;
+    size_t n = 0;
+    int rc = mico_wsi_compress_tile(rgb, w, h, out + 12, cap - 12, &n);
+    if (rc) return rc;
+    memcpy(out, "MICR", 4); put32(out + 4, (uint32_t)w); put32(out + 8, (uint32_t)h);
+    *out_len = 12 + n;
+    return MICO_OK;
+}
+int mico_micr_read(const uint8_t *in, size_t len, uint8_t *rgb, size_t cap, int *w, int *h) {
+    if (len < 12 || memcmp(in, "MICR", 4) != 0) return MICO_ERR_CORRUPT;
+    *w = (int)get32(in + 4); *h = (int)get32(in + 8);
+    if (*w <= 0 || *h <= 0) return MICO_ERR_CORRUPT;
+    if ((size_t)*w * (size_t)*h * 3 > cap) return MICO_ERR_CAPACITY;
+    return mico_wsi_decompress_tile(in + 12, len - 12, *w, *h, rgb);
+}
+int mico_mic1_write(const uint16_t *px, int w, int h, uint16_t max_value, int nstates, uint8_t *out, size_t cap, size_t *out_len) {
+    if (cap < 20) return MICO_ERR_CAPACITY;
+    size_t n = 0;
+    int rc = mico_compress_single_frame(px, w, h, max_value, nstates, out + 20, cap - 20, &n);
+    if (rc) return rc;
+    memcpy(out, "MIC1", 4); put32(out + 4, (uint32_t)w); put32(out + 8, (uint32_t)h); put32(out + 12, 1); put32(out + 16, (uint32_t)n);
+    *out_len = 20 + n;
+    return MICO_OK;
+}
+int mico_mic1_read(const uint8_t *in, size_t len, uint16_t *px, size_t cap_px, int *w, int *h) {
+    if (len < 20 || memcmp(in, "MIC1", 4) != 0 || get32(in + 12) != 1) return MICO_ERR_CORRUPT;
+    *w = (int)get32(in + 4); *h = (int)get32(in + 8);
+    size_t n = get32(in + 16);
+    if (*w <= 0 || *h <= 0 || n > len - 20) return MICO_ERR_CORRUPT;
+    if ((size_t)*w * (size_t)*h > cap_px) return MICO_ERR_CAPACITY;
+    return mico_decompress_single_frame(in + 20, n, px, *w, *h);
+}
+
 /* bytesToUint16Slice / uint16ToBytes, wsicompress.go:573-603: one byte per sample up to 8 bits, else little-endian pairs */
 static uint16_t sample_get(const uint8_t *p, size_t i, int bps) { return bps <= 8 ? p[i] : (uint16_t)(p[2 * i] | (p[2 * i + 1] << 8)); }
 static void sample_put(uint8_t *p, size_t i, int bps, uint16_t v) { if (bps <= 8) p[i] = (uint8_t)v; else { p[2 * i] = (uint8_t)v; p[2 * i + 1] = (uint8_t)(v >> 8); } }

@@ -229,6 +229,42 @@ def wsi_compress(rgb: np.ndarray, tile_w: int = 256, tile_h: int = 256, levels: 
     return rc, (out[: n.value].tobytes() if rc == 0 else b"")
 
 
+def micr_write(rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty(rgb.size * 4 + 4096, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_micr_write(_p(rgb), w, h, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def micr_read(b: bytes):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    w, h = int.from_bytes(bytes(b[4:8]), "little"), int.from_bytes(bytes(b[8:12]), "little")
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    cw, ch = C.c_int(), C.c_int()
+    rc = lib().mico_micr_read(_p(a), C.c_size_t(a.size), _p(out), C.c_size_t(out.size), C.byref(cw), C.byref(ch))
+    return rc, (out if rc == 0 else None)
+
+
+def mic1_write(px: np.ndarray, max_value: int, nstates: int = 2):
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w = px.shape
+    out = np.empty(px.size * 2 + 8192, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_mic1_write(_p(px), w, h, C.c_uint16(max_value), nstates, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def mic1_read(b: bytes):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    w, h = int.from_bytes(bytes(b[4:8]), "little"), int.from_bytes(bytes(b[8:12]), "little")
+    out = np.empty((h, w), dtype=np.uint16)
+    cw, ch = C.c_int(), C.c_int()
+    rc = lib().mico_mic1_read(_p(a), C.c_size_t(a.size), _p(out), C.c_size_t(out.size), C.byref(cw), C.byref(ch))
+    return rc, (out if rc == 0 else None)
+
+
 def wsi_compress_grey(img: np.ndarray, tile_w: int = 256, tile_h: int = 256, levels: int = 0):
     """CompressWSI with channels=1; uint8 -> 8 bits per sample, uint16 -> 16 (little-endian bytes)."""
     bps = 16 if img.dtype == np.uint16 else 8

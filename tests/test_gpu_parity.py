@@ -471,6 +471,32 @@ def test_wsi_greyscale_noise_errors_and_raw_planes(mic, mico, synth, gpu_ready):
     assert e.value.code == mic.MIC_ERR_UNSUPPORTED
 
 
+def test_rgb_and_single_frame_files(mic, mico, synth, gpu_ready):
+    """CompressRGB / DecompressRGB (rgbcompress.go:25-33) and the CLI's MICR / MIC1 files (cmd/mic-compress/main.go:26-91)."""
+    img = np.ascontiguousarray(synth.wsi_like(300, 200, seed=3))
+    rc, want = mico.wsi_compress_tile(img)
+    assert rc == 0
+    got = mic.compress_rgb(img, 300, 200)
+    assert got == want and np.array_equal(mic.decompress_rgb(got, 300, 200), img)
+    rc, wantf = mico.micr_write(img)
+    assert rc == 0 and mic.compress_rgb(img, 300, 200, container=True) == wantf
+    assert np.array_equal(mic.decompress_rgb(wantf), img)
+    white = np.full((64, 48, 3), 255, np.uint8)                                  # three constant planes: 12 + 3 + 1 + 1 bytes
+    assert len(mic.compress_rgb(white, 48, 64)) == 17 and np.array_equal(mic.decompress_rgb(mic.compress_rgb(white, 48, 64), 48, 64), white)
+    big = np.ascontiguousarray(synth.wsi_like(1920, 1080, seed=12))              # one 2-megapixel "tile" per plane
+    rc, want = mico.wsi_compress_tile(big)
+    assert rc == 0 and mic.compress_rgb(big, 1920, 1080) == want
+    assert np.array_equal(mic.decompress_rgb(want, 1920, 1080), big)
+    mr = np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
+    for ns in (2, 4, 8):
+        rc, wantf = mico.mic1_write(mr, int(mr.max()), ns)
+        assert rc == 0 and mic.write_mic1(mr, 256, 256, int(mr.max()), ns) == wantf
+        assert np.array_equal(mic.read_mic1(wantf), mr)
+    for bad in (b"MIC1" + bytes(16), b"MIC1" + bytes(8) + (1).to_bytes(4, "little") + (99).to_bytes(4, "little"), b"MICR" + bytes(8), b"nope"):
+        with pytest.raises(mic.MicError):
+            (mic.read_mic1 if bad[:4] == b"MIC1" else mic.decompress_rgb)(bad)
+
+
 def test_wsi_white_slide_is_101_bytes(mic, gpu_ready):
     white = np.full((256, 256, 3), 255, dtype=np.uint8)
     blob = mic.compress_wsi(white, 256, 256)

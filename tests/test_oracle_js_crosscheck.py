@@ -55,6 +55,13 @@ def test_js_decoder_accepts_oracle_streams(mico, synth, tmp_path):
     rc, blob = mico.wsi_compress(img)
     assert rc == 0
     add("file", blob, img)
+    rc, blob = mico.micr_write(img[:200, :280])               # MICR: header + CompressRGB blob
+    assert rc == 0
+    add("file", blob, np.ascontiguousarray(img[:200, :280]))
+    for ns in (2, 4, 8):                                      # MIC1: header + CompressSingleFrame{,4State,8State}
+        rc, blob = mico.mic1_write(mr, mx, ns)
+        assert rc == 0
+        add("file", blob, mr)
     _run(tmp_path, jobs)
     for p_out, arr in want:
         got = np.frombuffer(p_out.read_bytes(), dtype=arr.dtype)

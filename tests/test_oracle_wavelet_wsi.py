@@ -206,3 +206,24 @@ def test_wsi_greyscale_noise(mico, synth):
     for img in (n16[:40, :56], (n16[:40, :56] >> 8).astype(np.uint8)):
         rc, t = mico.wsi_decompress_tile_at(grey_raw_container(img), 0, 0, 0, 56, 40)
         assert rc == 0 and np.array_equal(t, img)
+
+
+# ---- CompressRGB + the CLI's MIC1 / MICR files (rgbcompress.go:25-33, cmd/mic-compress/main.go:26-91) ----
+def test_micr_and_mic1_files(mico, synth):
+    img = np.ascontiguousarray(synth.wsi_like(300, 200, seed=3))
+    rc, blob = mico.micr_write(img)
+    assert rc == 0 and blob[:4] == b"MICR" and blob[4:12] == (300).to_bytes(4, "little") + (200).to_bytes(4, "little")
+    rc, tile = mico.wsi_compress_tile(img)                                       # CompressRGB is the tile blob of the whole image
+    assert rc == 0 and blob[12:] == tile
+    rc, back = mico.micr_read(blob)
+    assert rc == 0 and np.array_equal(back, img)
+    mr = np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
+    for ns in (2, 4, 8):
+        rc, f = mico.mic1_write(mr, int(mr.max()), ns)
+        assert rc == 0 and f[:4] == b"MIC1" and f[12:16] == (1).to_bytes(4, "little")
+        assert int.from_bytes(f[16:20], "little") == len(f) - 20
+        rc, frame = mico.compress_single_frame(mr, int(mr.max()), ns)
+        assert rc == 0 and f[20:] == frame
+        rc, back = mico.mic1_read(f)
+        assert rc == 0 and np.array_equal(back, mr)
+    assert mico.mic1_read(b"MIC1" + bytes(16))[0] != 0 and mico.micr_read(b"MICX" + bytes(20))[0] != 0
