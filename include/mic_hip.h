@@ -125,6 +125,24 @@ int mic_hip_pics_info(const uint8_t *compressed, size_t compressed_len,
 int mic_hip_pics_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *pixels_out, int width, int height);
 
+/* Replaces CompressSingleFrameGrad / DecompressSingleFrameGrad (multiframecompress.go:111-142): the unit codec with the
+ * gradient-adaptive predictor (deltagradrlecompressu16.go) and the two-state -> one-state FSE chain. */
+int mic_hip_compress_frame_grad(const uint16_t *pixels, int width, int height, uint16_t max_value,
+                                uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_decompress_frame_grad(const uint8_t *compressed, size_t compressed_len,
+                                  uint16_t *pixels_out, int width, int height);
+
+/* ---- PICA container: content-adaptive strips, per-strip predictor choice ------------------------ */
+/* Replaces CompressParallelStripsAdaptive (parallelstripsadaptive.go:54): strip boundaries by equal-cost partition of the rows'
+ * summed |vertical delta| (adaptiveStripBoundaries, :222-289, float64 like the reference), every strip coded with both the avg
+ * and the gradient-adaptive predictor (CompressSingleFrame / CompressSingleFrameGrad, two-state FSE) and the smaller kept, ties to
+ * the gradient one (:97-105).  num_strips must be given (the reference's default is GOMAXPROCS). */
+int mic_hip_pica_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips,
+                          uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_pica_info(const uint8_t *compressed, size_t compressed_len, int *width, int *height, int *num_strips);
+/* Replaces DecompressParallelStripsAdaptive (parallelstripsadaptive.go:141). */
+int mic_hip_pica_decompress(const uint8_t *compressed, size_t compressed_len, uint16_t *pixels_out, int width, int height);
+
 /* ---- MIC2 container, independent frames --------------------------------------------------- */
 /* Replaces CompressMultiFrame(..., temporal=false) (multiframecompress.go:179) +
  * WriteMIC2 (multiframe.go:49).  frames = nframes*width*height u16, frame-major. */
@@ -225,8 +243,12 @@ typedef struct mic_hip_unit {
     uint64_t px_offset;     /* first pixel of the unit, in u16 elements from d_pixels */
     int32_t  width, height;
     uint16_t max_value;
-    uint16_t nstates;
+    uint16_t nstates;       /* 2 / 4 / 8, optionally | MIC_HIP_PRED_GRAD */
 } mic_hip_unit;
+/* OR'ed into mic_hip_unit.nstates: the unit uses the gradient-adaptive predictor of CompressSingleFrameGrad /
+ * DecompressSingleFrameGrad (multiframecompress.go:111-142, deltagradrlecompressu16.go) instead of avg(left, top).  The
+ * stream does not record its predictor (PICA keeps it in the strip's flags word), so decode units must carry it too. */
+#define MIC_HIP_PRED_GRAD 0x200
 
 /* Encode n units.  Compressed blobs are left in the session; *d_blobs receives the device
  * address of a packed buffer holding them back to back, h_offsets[n+1] (host) their byte

@@ -89,6 +89,7 @@ ABI_SYMBOLS = [
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
+    "mic_hip_compress_frame_grad", "mic_hip_decompress_frame_grad", "mic_hip_pica_compress", "mic_hip_pica_info", "mic_hip_pica_decompress",
     "mic_hip_rgb_compress", "mic_hip_rgb_decompress", "mic_hip_micr_compress", "mic_hip_micr_info", "mic_hip_micr_decompress",
     "mic_hip_mic1_compress", "mic_hip_mic1_info", "mic_hip_mic1_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
@@ -140,6 +141,11 @@ def lib() -> C.CDLL:
     L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_compress_frame_grad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_decompress_frame_grad.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    L.mic_hip_pica_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_pica_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 3
+    L.mic_hip_pica_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
     L.mic_hip_rgb_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_rgb_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.mic_hip_micr_compress.argtypes = L.mic_hip_rgb_compress.argtypes
@@ -461,6 +467,59 @@ def decompress_wsi_level(compressed, level: int = 0) -> np.ndarray:
     if rc:
         _raise(rc, "decompress_wsi_level")
     return _wsi_shape(hdr, out, lv["width"], lv["height"])
+
+
+# ------------------------------------------------------------------ gradient predictor, PICA
+def compress_single_frame_grad(pixels, width: int, height: int, max_value: int) -> bytes:
+    """CompressSingleFrameGrad (multiframecompress.go:111)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
+    if px.size != width * height:
+        raise MicError(MIC_ERR_ARGS, "compress_single_frame_grad")
+    cap = px.size * 2 + 8192
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_compress_frame_grad(px.ctypes.data, width, height, max_value, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_single_frame_grad")
+    return out[: n.value].tobytes()
+
+
+def decompress_single_frame_grad(compressed, width: int, height: int) -> np.ndarray:
+    """DecompressSingleFrameGrad (multiframecompress.go:132)."""
+    c = _bytes_arr(compressed)
+    out = np.empty(width * height, dtype=np.uint16)
+    rc = lib().mic_hip_decompress_frame_grad(c.ctypes.data, c.size, out.ctypes.data, width, height)
+    if rc:
+        _raise(rc, "decompress_single_frame_grad")
+    return out.reshape(height, width)
+
+
+def compress_parallel_strips_adaptive(pixels, width: int, height: int, max_value: int, num_strips: int) -> bytes:
+    """CompressParallelStripsAdaptive (parallelstripsadaptive.go:54)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
+    if px.size != width * height:
+        raise MicError(MIC_ERR_ARGS, "compress_parallel_strips_adaptive")
+    cap = px.size * 2 + 8192 * max(1, num_strips) + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().mic_hip_pica_compress(px.ctypes.data, width, height, max_value, num_strips, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc, "compress_parallel_strips_adaptive")
+    return out[: n.value].tobytes()
+
+
+def decompress_parallel_strips_adaptive(compressed) -> np.ndarray:
+    """DecompressParallelStripsAdaptive (parallelstripsadaptive.go:141): (height, width) uint16."""
+    c = _bytes_arr(compressed)
+    w, h, n = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_pica_info(c.ctypes.data, c.size, C.byref(w), C.byref(h), C.byref(n))
+    if rc:
+        _raise(rc, "decompress_parallel_strips_adaptive")
+    out = np.empty(w.value * h.value, dtype=np.uint16)
+    rc = lib().mic_hip_pica_decompress(c.ctypes.data, c.size, out.ctypes.data, w.value, h.value)
+    if rc:
+        _raise(rc, "decompress_parallel_strips_adaptive")
+    return out.reshape(h.value, w.value)
 
 
 # ------------------------------------------------------------------ single-frame RGB, MIC1 / MICR files

@@ -45,19 +45,21 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
     int rc = s->ensure(n, max_px);
     if (rc) return rc;
     s->h_units.assign((size_t)n, MicUnit{});
+    bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
         u.px_in = d_pixels + units[i].px_offset;
         u.w = units[i].width; u.h = units[i].height;
-        u.max_value = units[i].max_value; u.nstates = units[i].nstates;
+        u.max_value = units[i].max_value; u.nstates = units[i].nstates & 0xFF;
+        u.pred = (units[i].nstates & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
         s->fill_workspace(u, i);
         u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
-        if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8)) return MIC_ERR_ARGS;
+        if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8) || (units[i].nstates & ~(0xFF | MIC_HIP_PRED_GRAD))) return MIC_ERR_ARGS;
     }
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant, &s->timer);
+    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
     HIP_TRY(hipGetLastError());
     s->n_last = n;
     return MIC_OK;
@@ -99,6 +101,7 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
     int rc = s->ensure(n, max_px);
     if (rc) return rc;
     s->h_units.assign((size_t)n, MicUnit{});
+    bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
         uint64_t len = h_offsets[i + 1] - h_offsets[i];
@@ -106,13 +109,14 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
         u.comp_in = d_blobs + h_offsets[i]; u.comp_len = (uint32_t)len;
         u.px_out = d_pixels_out + units[i].px_offset;
         u.w = units[i].width; u.h = units[i].height;
+        u.pred = (units[i].nstates & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
         s->fill_workspace(u, i);
         u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
     }
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, &s->timer);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
     HIP_TRY(hipGetLastError());
     s->n_last = n;
     return MIC_OK;

@@ -201,9 +201,12 @@ __global__ void __launch_bounds__(64) k_dec_pixels_serial(MicUnit *units) {
             } else {
                 int32_t diff = (int32_t)v - (int32_t)thr;
                 int32_t prev = 0; int div = 0;
-                if (x > 0) { prev = out[idx - 1]; div++; }
-                if (y > 0) { prev += out[idx - w]; div++; }
-                if (div == 2) prev >>= 1;
+                if (u.pred) prev = mic_grad_predict_at(out, w, x, y);
+                else {
+                    if (x > 0) { prev = out[idx - 1]; div++; }
+                    if (y > 0) { prev += out[idx - w]; div++; }
+                    if (div == 2) prev >>= 1;
+                }
                 out[idx] = (uint16_t)(prev + diff);
             }
             if (r.err) { u.status = MICD_ERR_CORRUPT; return; }
@@ -976,6 +979,8 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream, MicTime
 }
 
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
+    const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
+    variant &= ~MIC_VARIANT_GRAD;
     if (variant == 100) {
         if (t) t->mark("k_dec_tables");
         hipLaunchKernelGGL(k_dec_tables, dim3(n), dim3(256), 0, stream, d_units);
@@ -1023,7 +1028,7 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         if (t) t->mark("k_dec_pixels_serial");
         hipLaunchKernelGGL(k_dec_pixels_serial, dim3(n), dim3(64), 0, stream, d_units);
     } else {
-        mic_launch_decode_pixels(d_units, n, stream, t);
+        mic_launch_decode_pixels(d_units, n, stream, t, any_grad);
     }
     if (t) t->mark("end");
 }

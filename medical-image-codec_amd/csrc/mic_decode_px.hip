@@ -325,6 +325,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
     // steps ahead so the L2 round trip is off the step's critical path.
     // Frames up to PR_MAX_W columns leave here: k_dec_predict does this phase one wave per unit.
     if (W <= PR_MAX_W) return;
+    if (u.pred) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // the gradient predictor has no in-group wavefront
     const int ngrp = (W + PX_K - 1) / PX_K;
     for (int rb = 0; rb < H; rb += PX_THREADS) {
         const int y = rb + (int)tid;
@@ -456,7 +457,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
     const int ui = (int)blockIdx.x * WPG + (int)(threadIdx.x >> 6);
     if (ui >= n_units) return;
     MicUnit &u = units[ui];
-    if (u.status != MICD_OK || u.mode != 0) return;
+    if (u.status != MICD_OK || u.mode != 0 || u.pred) return;
     const int W = u.w, H = u.h;
     if (W <= w_lo || W > w_hi) return;
     extern __shared__ uint32_t s_rowbuf_all[];                   // per wave: ngrp x PR_DW dwords
@@ -603,7 +604,117 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
     }
 }
 
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t) {
+// ------------------------------------------------------------------------------------------
+// Inverse gradient-adaptive predictor (GradDeltaRleDecompressU16.Decompress, deltagradrlecompressu16.go:70-133) for units with
+// pred = 1 (PICA strips flagged picaFlagGradPredictor).  Input as for k_dec_predict: px_out holds each pixel's delta symbol (or the
+// raw value where its flag bit is set).  One wave per unit, lane r owns row 64 b + r of band b and lags the row above by one
+// four-pixel group: at step t it rebuilds columns 4 (t - r) .. + 3 from W = its own previous pixel, N / NW = the group lane r - 1
+// produced one step earlier (DPP wave_shr), and NE of the group's last pixel = the first pixel lane r - 1 produces in THIS step,
+// handed over in the middle of the step.  Lane 0 takes the row above from an LDS row buffer that lane 63 of the previous band
+// filled (wave-private, no barriers).  Symbols are fetched one step ahead as 8-byte vectors.
+#define PG_Q 4
+__global__ void __launch_bounds__(64) k_dec_predict_grad(MicUnit *units, int w_lo, int w_hi) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.mode != 0 || !u.pred) return;
+    const int W = u.w, H = u.h;
+    if (W <= w_lo || W > w_hi) return;                           // row-buffer class of this launch (wider than PR_MAX_W: k_dec_pixels_wg has flagged it)
+    extern __shared__ uint16_t s_grow[];                         // the last row of the previous band (+ PG_Q slack)
+    const uint32_t lane = threadIdx.x;
+    const int32_t thr = (int32_t)u.dec_thr;
+    const pr_gu16 px = (pr_gu16)u.px_out;
+    const __attribute__((address_space(1))) uint32_t *flags = (const __attribute__((address_space(1))) uint32_t *)u.flags;
+    const int nq = (W + PG_Q - 1) / PG_Q;                        // groups per row
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    for (int x = (int)lane; x < nq * PG_Q + PG_Q; x += 64) s_grow[x] = 0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    struct Grp { uint32_t v[PG_Q]; uint32_t raw; };              // symbols of a group and the raw bits of its pixels
+    for (int y0 = 0; y0 < H; y0 += 64) {
+        const int y = y0 + (int)lane;
+        const bool row_ok = y < H;
+        const uint32_t rowp = (uint32_t)y * (uint32_t)W;
+        auto fetch = [&](int q) -> Grp {
+            Grp g; g.raw = 0;
+#pragma unroll
+            for (int k = 0; k < PG_Q; k++) g.v[k] = 0;
+            if (!row_ok || q < 0 || q >= nq) return g;
+            const uint32_t p = rowp + (uint32_t)q * PG_Q;
+            if (p + PG_Q <= npx) {
+                const pr_v2 d = *(const __attribute__((address_space(1))) PrD *)(px + p);
+                g.v[0] = d.x & 0xFFFFu; g.v[1] = d.x >> 16; g.v[2] = d.y & 0xFFFFu; g.v[3] = d.y >> 16;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PG_Q; k++) if (p + (uint32_t)k < npx) g.v[k] = px[p + (uint32_t)k];
+            }
+            const uint32_t w0 = flags[p >> 5], w1 = flags[(p >> 5) + 1];   // (the flag slab has a spare word behind the last pixel)
+            g.raw = __builtin_amdgcn_alignbit(w1, w0, p) & 0xFu;
+            return g;
+        };
+        uint32_t left = 0;                                       // W of the next pixel
+        uint32_t top[PG_Q] = { 0u, 0u, 0u, 0u };                 // the row above at this step's columns (set below)
+        uint32_t nw = 0;                                         // ... and at the column before them
+        uint32_t mine[PG_Q] = { 0u, 0u, 0u, 0u };                // this lane's previous result
+        Grp nx = fetch(-(int)lane);
+        const int steps = nq + 63;
+        for (int t = 0; t < steps; t++) {
+            const int q = t - (int)lane;
+            const Grp g = nx;
+            nx = fetch(q + 1);
+            const bool act = row_ok && q >= 0 && q < nq;
+            // N of the four columns: what lane r - 1 produced in the previous step; lane 0: the row buffer
+            uint32_t up[PG_Q];
+            {
+                const int qc = min(max(q, 0), nq - 1);
+                uint32_t rb0 = 0, rb1 = 0;
+                if (lane == 0) { const uint2 r = *(const uint2 *)(s_grow + qc * PG_Q); rb0 = r.x; rb1 = r.y; }
+                const uint32_t m0 = mine[0] | (mine[1] << 16), m1 = mine[2] | (mine[3] << 16);
+                const uint32_t t0 = __builtin_amdgcn_update_dpp(rb0, m0, 0x138, 0xF, 0xF, false);   // wave_shr:1
+                const uint32_t t1 = __builtin_amdgcn_update_dpp(rb1, m1, 0x138, 0xF, 0xF, false);
+                up[0] = t0 & 0xFFFFu; up[1] = t0 >> 16; up[2] = t1 & 0xFFFFu; up[3] = t1 >> 16;
+            }
+            const uint32_t x0 = (uint32_t)max(q, 0) * PG_Q;
+            uint32_t res[PG_Q];
+            auto pixel = [&](int k, uint32_t ne) {
+                const uint32_t x = x0 + (uint32_t)k;
+                int32_t pred;
+                if (y == 0) pred = x ? (int32_t)left : 0;                            // first row: left only, corner 0 (:81-91)
+                else if (x == 0) pred = (int32_t)up[0];                              // first column: top only (:97-104)
+                else pred = mic_grad_predict((int32_t)left, (int32_t)up[k], (int32_t)(k ? up[k - 1] : nw), (int32_t)ne);
+                const uint32_t r = ((g.raw >> k) & 1u) ? g.v[k] : (uint32_t)(pred + (int32_t)g.v[k] - thr) & 0xFFFFu;
+                res[k] = r; left = r;
+            };
+            // columns 0..2: NE is the next column of the same group above; at the right edge NE = NW (:113-116)
+#pragma unroll
+            for (int k = 0; k < PG_Q - 1; k++) {
+                const uint32_t x = x0 + (uint32_t)k;
+                const uint32_t nwk = k ? up[k - 1] : nw;
+                pixel(k, (x + 1 < (uint32_t)W) ? up[k + 1] : nwk);
+            }
+            // column 3: NE is the first pixel lane r - 1 has just produced for ITS group (one group further right)
+            {
+                uint32_t rb = 0;
+                if (lane == 0) rb = s_grow[min(q + 1, nq) * PG_Q];
+                const uint32_t ne_in = __builtin_amdgcn_update_dpp(rb, res[0], 0x138, 0xF, 0xF, false);
+                const uint32_t x = x0 + 3u;
+                pixel(3, (x + 1 < (uint32_t)W) ? ne_in : up[2]);
+            }
+            nw = up[PG_Q - 1];
+            if (act) {
+                const uint32_t p = rowp + (uint32_t)q * PG_Q;
+                const int cnt = min(PG_Q, W - q * PG_Q);
+                const uint32_t d0 = res[0] | (res[1] << 16), d1 = res[2] | (res[3] << 16);
+                if (cnt == PG_Q) { pr_v2 d; d.x = d0; d.y = d1; *(__attribute__((address_space(1))) PrD *)(px + p) = d; }
+                else for (int k = 0; k < cnt; k++) px[p + (uint32_t)k] = (uint16_t)res[k];
+                if (lane == 63) *(uint2 *)(s_grow + q * PG_Q) = make_uint2(d0, d1);   // the next band's row above (read 63 steps ahead of this write)
+            }
+#pragma unroll
+            for (int k = 0; k < PG_Q; k++) mine[k] = act ? res[k] : mine[k];
+            if (!act) { left = 0; if (q < 0) nw = 0; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                        // wave-private LDS: lane 63's row is in before the next band reads it
+    }
+}
+
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad) {
     if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
     // two row-buffer classes so that ordinary widths keep many waves per CU
@@ -611,4 +722,11 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 0, 8192 - PR_K);
     if (t) t->mark("k_dec_predict<wide>");
     hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W);
+    if (any_grad) {
+        if (t) t->mark("k_dec_predict_grad");
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dec_predict_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (PR_MAX_W + 2 * PG_Q) * 2); attr_done = true; }
+        hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - 2 * PG_Q);
+        hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), (PR_MAX_W + 2 * PG_Q) * 2, stream, d_units, 8192 - 2 * PG_Q, PR_MAX_W);
+    }
 }

@@ -34,6 +34,7 @@ struct MicUnit {
     uint16_t        nstates;  // encode: requested flavour 1/2/4/8, 108 = rANS-8
     uint32_t        mode;     // 0 = frame (Delta+RLE around the FSE stage), 1 = bare FSE: px_in / px_out hold u16 symbols, w = count
     uint32_t        no_fallback; // 1 = FSECompressU16* semantics (no N -> ... -> 1 chain)
+    uint32_t        pred;     // mode 0: 0 = avg(left, top) predictor, 1 = gradient-adaptive (deltagradrlecompressu16.go)
     // ---- per-unit workspace (HBM) ------------------------------------------------
     uint16_t *tok;            // RLE token stream (encode: produced, decode: FSE output)
     uint32_t  tok_cap;
@@ -81,6 +82,20 @@ struct MicUnit {
 #endif
 
 __device__ __forceinline__ int mic_len16(uint32_t v) { return v ? 32 - __clz(v) : 0; }
+// gradPredict (deltagradcompressu16.go:147-167): avg(W, N) + clamp((NE - NW) >> 3, +-(|W - NW| + |N - NW|) / 2); no gradient, no correction
+__device__ __forceinline__ int32_t mic_grad_predict(int32_t w, int32_t n, int32_t nw, int32_t ne) {
+    const int32_t lim = (int32_t)((__sad((unsigned)w, (unsigned)nw, 0u) + __sad((unsigned)n, (unsigned)nw, 0u)) >> 1);
+    const int32_t corr = (ne - nw) >> 3;
+    return ((w + n) >> 1) + min(max(corr, -lim), lim);
+}
+// the gradient-adaptive prediction of pixel (x, y) from a plain pixel array (deltagradrlecompressu16.go:36-53)
+__device__ __forceinline__ int32_t mic_grad_predict_at(const uint16_t *px, int w, int x, int y) {
+    const size_t idx = (size_t)y * (size_t)w + (size_t)x;
+    if (y == 0) return x ? (int32_t)px[idx - 1] : 0;
+    if (x == 0) return (int32_t)px[idx - (size_t)w];
+    const int32_t nw = px[idx - (size_t)w - 1];
+    return mic_grad_predict(px[idx - 1], px[idx - (size_t)w], nw, (x + 1 < w) ? (int32_t)px[idx - (size_t)w + 1] : nw);
+}
 // fseu16.go:170-172 -- Len32(v)-1, wraps to 0xFFFFFFFF for 0
 __device__ __forceinline__ uint32_t mic_high_bits(uint32_t v) { return (uint32_t)(31 - __clz(v)) ; }
 __device__ __forceinline__ uint32_t mic_table_step(uint32_t size) { return (size >> 1) + (size >> 3) + 3; }

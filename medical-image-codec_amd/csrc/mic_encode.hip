@@ -100,9 +100,12 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
         for (int x = 0; x < w; x++) {
             size_t idx = (size_t)y * w + x;
             int32_t prev = 0; int div = 0;
-            if (x > 0) { prev = in[idx - 1]; div++; }
-            if (y > 0) { prev += in[idx - w]; div++; }
-            if (div == 2) prev >>= 1;
+            if (u.pred) prev = mic_grad_predict_at(in, w, x, y);
+            else {
+                if (x > 0) { prev = in[idx - 1]; div++; }
+                if (y > 0) { prev += in[idx - w]; div++; }
+                if (div == 2) prev >>= 1;
+            }
             uint16_t val = in[idx];
             int32_t diff = (int32_t)val - prev;
             int32_t m = diff >> 31;
@@ -181,9 +184,12 @@ typedef tk_v2 TkD __attribute__((aligned(2)));                 // 4 pixels, 2-by
 // SRC 0: frame units (mode 0) -- symbols are the Delta(avg) residuals of the pixels, stream = [delim][RLE(maxValue, symbols)].
 // SRC 1: RLE-of-symbols units (mode 2, wavelet / residual paths) -- RleCompressU16.Init(len,1,max).Compress(symbols)
 //        (rlecompressu16.go:85-93): symbols come from u.sym[0..u.nsym), stream = [max][len>>16][len&0xFFFF][RLE(symbols)].
-template <int SRC>
+// PRED (frame units only) 1: the gradient-adaptive predictor of GradDeltaRleCompressU16 (deltagradrlecompressu16.go:26-68) -- the
+//        same stream with mic_grad_predict(W, N, NW, NE) in place of avg(W, N); units with u.pred == 1 (PICA's second encode).
+template <int SRC, int PRED = 0>
 __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
+    if (!SRC && u.pred != (uint32_t)PRED) return;
     __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per tile parity: [0..5] = 6 symbols before the tile, [6..] = new symbols
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16], s_run[16], s_str[16], s_tc[16];   // per-wave partials (unused tail stays 0)
     __shared__ uint32_t s_ovf, s_last[2];
@@ -240,11 +246,11 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     }
     __syncthreads();
     // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile)
-    struct TkFetch { tk_v2 cv, tv; uint32_t lft, x, y; bool row4; };
+    struct TkFetch { tk_v2 cv, tv; uint32_t lft, tl, tr, x, y; bool row4; };
     const uint32_t tile_dy = TP / W, tile_dx = TP - tile_dy * W;   // a tile further on: tile_dy rows and tile_dx columns
     uint32_t ny = (tid * TK_PPT) / W, nx = tid * TK_PPT - ny * W;  // position of this thread's first pixel in the next tile to fetch
     auto fetch = [&](uint32_t tile) -> TkFetch {
-        TkFetch f; f.cv = tk_v2{0u, 0u}; f.tv = tk_v2{0u, 0u}; f.lft = 0; f.x = 0; f.y = 0; f.row4 = false;
+        TkFetch f; f.cv = tk_v2{0u, 0u}; f.tv = tk_v2{0u, 0u}; f.lft = 0; f.tl = 0; f.tr = 0; f.x = 0; f.y = 0; f.row4 = false;
         const uint32_t gb = tile * TP + tid * TK_PPT;
         if (tile >= ntiles || gb >= npx) return f;
         if (SRC) {
@@ -259,6 +265,10 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
             f.cv = *(const TkD *)(in + gb);
             if (f.y > 0) f.tv = *(const TkD *)(in + gb - W);
             if (f.x > 0) f.lft = in[gb - 1];
+            if (PRED && f.y > 0) {                                  // NW of the first pixel, NE of the last (NE = NW at the right edge)
+                if (f.x > 0) f.tl = in[gb - W - 1];
+                f.tr = (f.x + TK_PPT < W) ? (uint32_t)in[gb - W + TK_PPT] : (f.tv.y & 0xFFFFu);
+            }
         }
         return f;
     };
@@ -289,9 +299,17 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
                     if (row4) {
                         val = cur[k];
                         const uint32_t l = k ? cur[k - 1] : f.lft;
-                        if (x + k > 0 && y > 0) prev = (int32_t)((l + top[k]) >> 1);
+                        if (x + k > 0 && y > 0) {
+                            if (PRED) prev = mic_grad_predict((int32_t)l, (int32_t)top[k], (int32_t)(k ? top[k - 1] : f.tl),
+                                                              (int32_t)(k + 1 < TK_PPT ? top[k + 1] : f.tr));
+                            else prev = (int32_t)((l + top[k]) >> 1);
+                        }
                         else if (x + k > 0) prev = (int32_t)l;
                         else prev = (int32_t)top[k];                        // 0 on row 0
+                    } else if (PRED) {
+                        const uint32_t yy = g / W, xx = g - yy * W;
+                        prev = mic_grad_predict_at(in, (int)W, (int)xx, (int)yy);
+                        val = in[g];
                     } else {
                         const uint32_t yy = g / W, xx = g - yy * W;
                         prev = 0;
@@ -1104,6 +1122,8 @@ __global__ void __launch_bounds__(1024) k_scan_lens(const MicUnit *units, int n,
 // ------------------------------------------------------------------------------------------
 // launchers
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
+    const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
+    variant &= ~MIC_VARIANT_GRAD;
     if (t) t->mark("k_enc_symbols");
     hipLaunchKernelGGL(k_enc_symbols, dim3(64, n), dim3(256), 0, stream, d_units);
     if (variant == 100) {
@@ -1113,6 +1133,7 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         if (t) t->mark("k_enc_tokens_wg");
         hipLaunchKernelGGL(k_enc_tokens_wg<0>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
         hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+        if (any_grad) hipLaunchKernelGGL((k_enc_tokens_wg<0, 1>), dim3(n), dim3(TK_THREADS), 0, stream, d_units);
     }
     if (variant == 100) {
         if (t) t->mark("k_enc_hist");

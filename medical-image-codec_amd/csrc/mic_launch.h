@@ -24,9 +24,12 @@ struct MicTimer {
 };
 
 // variant: 0 = default (fastest validated kernels), 100 = v0 single-lane reference kernels.
+// variant: 0 = the shipped kernels, 100 = the serial reference kernels; | MIC_VARIANT_GRAD when some unit has pred = 1 (their
+// tokeniser / predictor instantiations are only launched then)
+#define MIC_VARIANT_GRAD 0x1000
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t);
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false);
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream);
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream);

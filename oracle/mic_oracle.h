@@ -77,6 +77,19 @@ int mico_compress_single_frame(const uint16_t *px, int w, int h,
 int mico_decompress_single_frame(const uint8_t *in, size_t len,
                                  uint16_t *px, int w, int h);
 
+/* gradient-adaptive predictor variant (deltagradrlecompressu16.go, multiframecompress.go:111-142) */
+int mico_grad_delta_rle_compress(const uint16_t *px, int w, int h, uint16_t max_value,
+                                 uint16_t *out, size_t cap, size_t *out_n);
+int mico_grad_delta_rle_decompress(const uint16_t *in, size_t n, int width, int height, uint16_t *out);
+int mico_compress_single_frame_grad(const uint16_t *px, int w, int h, uint16_t max_value,
+                                    uint8_t *out, size_t cap, size_t *out_len);
+int mico_decompress_single_frame_grad(const uint8_t *in, size_t len, uint16_t *px, int w, int h);
+/* PICA: content-adaptive strips with per-strip predictor choice (parallelstripsadaptive.go:54-289) */
+int mico_pica_boundaries(const uint16_t *px, int w, int h, int num_strips, int *starts);
+int mico_pica_compress(const uint16_t *px, int w, int h, uint16_t max_value, int num_strips,
+                       uint8_t *out, size_t cap, size_t *out_len);
+int mico_pica_decompress(const uint8_t *in, size_t len, uint16_t *px, size_t px_cap, int *w, int *h);
+
 /* ---- L4: PICS strips (parallelstrips.go:55-330) ------------------------- */
 int mico_pics_compress(const uint16_t *px, int w, int h, uint16_t max_value,
                        int num_strips, int nstates,

@@ -171,9 +171,40 @@ int mico_rle_decompress(const uint16_t *in, size_t n, uint16_t *out, size_t cap,
 
 typedef void (*sym_sink)(void *ctx, uint16_t sym);
 
-/* deltarlecompressu16.go:24-61: predictor + threshold/escape, symbol by symbol */
-static int delta_walk(const uint16_t *in, int width, int height,
-                      uint16_t max_value, sym_sink sink, void *ctx) {
+/* gradPredict, deltagradcompressu16.go:147-167: avg(W, N) + clamp((NE - NW) >> 3, +-(|W - NW| + |N - NW|) / 2) */
+static int32_t iabs32(int32_t v) { int32_t m = v >> 31; return (v ^ m) - m; }
+static int32_t grad_predict(int32_t w, int32_t n, int32_t nw, int32_t ne) {
+    int32_t avg = (w + n) >> 1;
+    int32_t g = iabs32(w - nw) + iabs32(n - nw);
+    if (g == 0) return avg;
+    int32_t corr = (ne - nw) >> 3, limit = g >> 1;
+    if (corr > limit) corr = limit; else if (corr < -limit) corr = -limit;
+    return avg + corr;
+}
+/* the prediction of pixel (x, y) from pixels already known in px: pred 0 = avg(left, top) (deltarlecompressu16.go:33-46),
+ * pred 1 = gradient-adaptive (deltagradrlecompressu16.go:36-53: 0 at the corner, left on row 0, top in column 0, NE = NW at the
+ * right edge) */
+static int32_t predict_px(const uint16_t *px, int width, int x, int y, int pred) {
+    size_t index = (size_t)y * (size_t)width + (size_t)x;
+    if (pred == 0) {
+        int div = 0;
+        int32_t prev = 0;
+        if (x > 0) { prev = (int32_t)px[index - 1]; div++; }
+        if (y > 0) { prev += (int32_t)px[index - (size_t)width]; div++; }
+        if (div == 2) prev >>= 1;
+        return prev;
+    }
+    if (x == 0 && y == 0) return 0;
+    if (y == 0) return (int32_t)px[index - 1];
+    if (x == 0) return (int32_t)px[index - (size_t)width];
+    int32_t w = px[index - 1], n = px[index - (size_t)width], nw = px[index - (size_t)width - 1];
+    int32_t ne = (x + 1 < width) ? (int32_t)px[index - (size_t)width + 1] : nw;
+    return grad_predict(w, n, nw, ne);
+}
+
+/* deltarlecompressu16.go:24-61 / deltagradrlecompressu16.go:26-68: predictor + threshold/escape, symbol by symbol */
+static int delta_walk_pred(const uint16_t *in, int width, int height,
+                           uint16_t max_value, int pred, sym_sink sink, void *ctx) {
     int depth = len16(max_value);
     /* depth < 4: the Go tokeniser panics or emits empty chunks (rlecompressu16.go:57-67) */
     if (depth < 4 || width <= 0 || height <= 0) return MICO_ERR_ARGS;
@@ -183,11 +214,7 @@ static int delta_walk(const uint16_t *in, int width, int height,
     for (int y = 0; y < height; y++) {
         for (int x = 0; x < width; x++) {
             size_t index = (size_t)y * (size_t)width + (size_t)x;
-            int div = 0;
-            int32_t prev = 0;
-            if (x > 0) { prev = (int32_t)in[index - 1]; div++; }
-            if (y > 0) { prev += (int32_t)in[index - (size_t)width]; div++; }
-            if (div == 2) prev >>= 1;
+            int32_t prev = predict_px(in, width, x, y, pred);
             uint16_t v = in[index];
             int32_t diff = (int32_t)v - prev;
             int32_t mask = diff >> 31; /* deltacompressu16.go:122-126 abs */
@@ -203,7 +230,30 @@ static int delta_walk(const uint16_t *in, int width, int height,
     return MICO_OK;
 }
 
+static int delta_walk(const uint16_t *in, int width, int height, uint16_t max_value, sym_sink sink, void *ctx) {
+    return delta_walk_pred(in, width, height, max_value, 0, sink, ctx);
+}
+
 static void sink_rle(void *ctx, uint16_t s) { rle_encode((rle_enc *)ctx, s); }
+
+/* deltarlecompressu16.go:24-67 (pred 0), deltagradrlecompressu16.go:26-68 (pred 1) */
+static int delta_rle_compress_pred(const uint16_t *px, int w, int h, uint16_t max_value, int pred,
+                                   uint16_t *out, size_t cap, size_t *out_n) {
+    int depth = len16(max_value);
+    if (depth == 0) return MICO_ERR_ARGS;
+    uint16_t delim = (uint16_t)((1 << depth) - 1);
+    rle_enc r;
+    int rc = rle_init(&r, delim, out, cap); /* Out[0] = delim, raw */
+    if (rc) return rc;
+    rc = delta_walk_pred(px, w, h, max_value, pred, sink_rle, &r);
+    if (rc) { free(r.b); return rc; }
+    rle_flush(&r);
+    return rle_done(&r, out_n);
+}
+int mico_grad_delta_rle_compress(const uint16_t *px, int w, int h, uint16_t max_value,
+                                 uint16_t *out, size_t cap, size_t *out_n) {
+    return delta_rle_compress_pred(px, w, h, max_value, 1, out, cap, out_n);
+}
 
 /* deltarlecompressu16.go:24-67 */
 int mico_delta_rle_compress(const uint16_t *px, int w, int h, uint16_t max_value,
@@ -236,9 +286,9 @@ int mico_delta_symbols(const uint16_t *px, int w, int h, uint16_t max_value,
     return MICO_OK;
 }
 
-/* deltarlecompressu16.go:69-128 */
-int mico_delta_rle_decompress(const uint16_t *in, size_t n, int width, int height,
-                              uint16_t *out) {
+/* deltarlecompressu16.go:69-128 (pred 0), deltagradrlecompressu16.go:70-133 (pred 1) */
+static int delta_rle_decompress_pred(const uint16_t *in, size_t n, int width, int height, int pred,
+                                     uint16_t *out) {
     rle_dec r;
     int rc = rle_dec_init(&r, in, n);
     if (rc) return rc;
@@ -256,17 +306,19 @@ int mico_delta_rle_decompress(const uint16_t *in, size_t n, int width, int heigh
                 out[index] = rle_next2(&r);
             } else {
                 int32_t diff = (int32_t)v - (int32_t)thr;
-                int div = 0;
-                int32_t prev = 0;
-                if (x > 0) { prev = (int32_t)out[index - 1]; div++; }
-                if (y > 0) { prev += (int32_t)out[index - (size_t)width]; div++; }
-                if (div == 2) prev >>= 1;
-                out[index] = (uint16_t)(prev + diff);
+                out[index] = (uint16_t)(predict_px(out, width, x, y, pred) + diff);
             }
             if (r.err) return MICO_ERR_CORRUPT;
         }
     }
     return MICO_OK;
+}
+
+int mico_delta_rle_decompress(const uint16_t *in, size_t n, int width, int height, uint16_t *out) {
+    return delta_rle_decompress_pred(in, n, width, height, 0, out);
+}
+int mico_grad_delta_rle_decompress(const uint16_t *in, size_t n, int width, int height, uint16_t *out) {
+    return delta_rle_decompress_pred(in, n, width, height, 1, out);
 }
 
 /* ===================================================================== FSE */
@@ -952,6 +1004,32 @@ int mico_compress_single_frame(const uint16_t *px, int w, int h,
     return rc;
 }
 
+/* CompressSingleFrameGrad / DecompressSingleFrameGrad, multiframecompress.go:111-142: the gradient predictor in front of the same
+ * two-state -> one-state FSE chain */
+int mico_compress_single_frame_grad(const uint16_t *px, int w, int h, uint16_t max_value,
+                                    uint8_t *out, size_t cap, size_t *out_len) {
+    if (!px || w <= 0 || h <= 0) return MICO_ERR_ARGS;
+    size_t scap = 4 * (size_t)w * (size_t)h + 16;
+    uint16_t *sym = (uint16_t *)malloc(sizeof(uint16_t) * scap);
+    if (!sym) return MICO_ERR_NOMEM;
+    size_t n = 0;
+    int rc = mico_grad_delta_rle_compress(px, w, h, max_value, sym, scap, &n);
+    if (rc == MICO_OK) rc = fse_chain(sym, n, 2, out, cap, out_len);
+    free(sym);
+    return rc;
+}
+int mico_decompress_single_frame_grad(const uint8_t *in, size_t len, uint16_t *px, int w, int h) {
+    if (!in || !px || w <= 0 || h <= 0) return MICO_ERR_ARGS;
+    size_t scap = 4 * (size_t)w * (size_t)h + 16;
+    uint16_t *sym = (uint16_t *)malloc(sizeof(uint16_t) * scap);
+    if (!sym) return MICO_ERR_NOMEM;
+    size_t n = 0;
+    int rc = mico_fse_decompress_auto(in, len, sym, scap, &n);
+    if (rc == MICO_OK) rc = mico_grad_delta_rle_decompress(sym, n, w, h, px);
+    free(sym);
+    return rc;
+}
+
 /* DecompressSingleFrame, multiframecompress.go:97-107 */
 int mico_decompress_single_frame(const uint8_t *in, size_t len,
                                  uint16_t *px, int w, int h) {
@@ -1023,6 +1101,106 @@ int mico_pics_decompress(const uint8_t *in, size_t len, uint16_t *px,
         if (y1 > height) y1 = height;
         if (y0 >= height) return MICO_ERR_CORRUPT; /* Go: slice panic */
         int rc = mico_decompress_single_frame(in + start, sl, px + (size_t)y0 * (size_t)width, width, (int)(y1 - y0));
+        if (rc) return rc;
+    }
+    return MICO_OK;
+}
+
+/* ==================================================================== PICA */
+
+/* adaptiveStripBoundaries, parallelstripsadaptive.go:222-289: equal-cost partition of the rows by summed |vertical delta|,
+ * in float64 as the reference computes it.  starts[] has room for num_strips entries; returns the number of strips. */
+int mico_pica_boundaries(const uint16_t *px, int w, int h, int num_strips, int *starts) {
+    if (num_strips >= h) { for (int i = 0; i < h; i++) starts[i] = i; return h; }
+    if (num_strips == 1) { starts[0] = 0; return 1; }
+    double *cum = (double *)malloc(sizeof(double) * ((size_t)h + 1));
+    if (!cum) return MICO_ERR_NOMEM;
+    cum[0] = 0.0; cum[1] = 0.0;                                  /* rowCost[0] = 0 */
+    for (int y = 1; y < h; y++) {
+        uint64_t sum = 0;
+        for (int x = 0; x < w; x++) {
+            int32_t d = (int32_t)px[(size_t)y * w + x] - (int32_t)px[(size_t)(y - 1) * w + x];
+            sum += (uint64_t)(d < 0 ? -d : d);
+        }
+        cum[y + 1] = cum[y] + (double)sum;
+    }
+    volatile double total = cum[h];
+    starts[0] = 0;
+    if (total == 0) {
+        for (int i = 1; i < num_strips; i++) starts[i] = (int)((long long)i * h / num_strips);
+    } else {
+        for (int i = 1; i < num_strips; i++) {
+            volatile double prod = total * (double)i;             /* Go: total * float64(i) / float64(numStrips), left to right */
+            double target = prod / (double)num_strips;
+            int lo = starts[i - 1] + 1, hi = h;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cum[mid] < target) lo = mid + 1; else hi = mid; }
+            if (lo >= h) lo = h - 1;
+            starts[i] = lo;
+        }
+    }
+    free(cum);
+    return num_strips;
+}
+
+/* CompressParallelStripsAdaptive, parallelstripsadaptive.go:54-137: per strip both predictors, the smaller blob wins (ties: gradient) */
+int mico_pica_compress(const uint16_t *px, int w, int h, uint16_t max_value, int num_strips,
+                       uint8_t *out, size_t cap, size_t *out_len) {
+    if (!px || w <= 0 || h <= 0) return MICO_ERR_ARGS;
+    if (num_strips <= 0) num_strips = 1; /* reference: GOMAXPROCS; callers pass it explicitly */
+    if (num_strips > h) num_strips = h;
+    int *starts = (int *)malloc(sizeof(int) * (size_t)num_strips);
+    if (!starts) return MICO_ERR_NOMEM;
+    int actual = mico_pica_boundaries(px, w, h, num_strips, starts);
+    if (actual < 0) { free(starts); return actual; }
+    size_t header = 16 + (size_t)actual * 16;
+    size_t scap = 4 * (size_t)w * (size_t)h + 4096;
+    uint8_t *ba = (uint8_t *)malloc(scap), *bg = (uint8_t *)malloc(scap);
+    int rc = (ba && bg) ? MICO_OK : MICO_ERR_NOMEM;
+    if (rc == MICO_OK && cap < header) rc = MICO_ERR_CAPACITY;
+    size_t offset = 0;
+    if (rc == MICO_OK) {
+        memcpy(out, "PICA", 4);
+        put_u32(out + 4, (uint32_t)w); put_u32(out + 8, (uint32_t)h); put_u32(out + 12, (uint32_t)actual);
+    }
+    for (int s = 0; s < actual && rc == MICO_OK; s++) {
+        int y0 = starts[s], y1 = (s + 1 < actual) ? starts[s + 1] : h;
+        size_t la = 0, lg = 0;
+        int r1 = mico_compress_single_frame(px + (size_t)y0 * w, w, y1 - y0, max_value, 2, ba, scap, &la);
+        int r2 = mico_compress_single_frame_grad(px + (size_t)y0 * w, w, y1 - y0, max_value, bg, scap, &lg);
+        const uint8_t *pick; size_t plen; uint32_t flags;
+        if (r2 == MICO_OK && (r1 != MICO_OK || lg <= la)) { pick = bg; plen = lg; flags = 1; }
+        else { pick = ba; plen = la; flags = 0; rc = r1; }
+        if (rc) break;
+        if (header + offset + plen > cap) { rc = MICO_ERR_CAPACITY; break; }
+        uint8_t *e = out + 16 + (size_t)s * 16;
+        put_u32(e, (uint32_t)y0); put_u32(e + 4, (uint32_t)offset); put_u32(e + 8, (uint32_t)plen); put_u32(e + 12, flags);
+        memcpy(out + header + offset, pick, plen);
+        offset += plen;
+    }
+    free(ba); free(bg); free(starts);
+    if (rc == MICO_OK) *out_len = header + offset;
+    return rc;
+}
+
+/* DecompressParallelStripsAdaptive, parallelstripsadaptive.go:141-214 */
+int mico_pica_decompress(const uint8_t *in, size_t len, uint16_t *px, size_t px_cap, int *w, int *h) {
+    if (len < 16 || memcmp(in, "PICA", 4) != 0) return MICO_ERR_CORRUPT;
+    int width = (int)get_u32(in + 4), height = (int)get_u32(in + 8), num_strips = (int)get_u32(in + 12);
+    if (num_strips < 0 || (size_t)num_strips > (len - 16) / 16) return MICO_ERR_CORRUPT;
+    size_t header = 16 + (size_t)num_strips * 16;
+    if (width <= 0 || height <= 0 || num_strips <= 0) return MICO_ERR_CORRUPT;
+    *w = width; *h = height;
+    if (!px) return MICO_OK;
+    if ((size_t)width * (size_t)height > px_cap) return MICO_ERR_CAPACITY;
+    for (int s = 0; s < num_strips; s++) {
+        const uint8_t *e = in + 16 + (size_t)s * 16;
+        long y0 = (long)get_u32(e), y1 = (s + 1 < num_strips) ? (long)get_u32(e + 16) : height;
+        size_t start = header + get_u32(e + 4), end = start + get_u32(e + 8);
+        uint32_t flags = get_u32(e + 12);
+        if (end > len || start > end) return MICO_ERR_CORRUPT;
+        if (y0 < 0 || y1 <= y0 || y1 > height) return MICO_ERR_CORRUPT;   /* Go: slice / make panics */
+        int rc = (flags & 1) ? mico_decompress_single_frame_grad(in + start, end - start, px + (size_t)y0 * width, width, (int)(y1 - y0))
+                             : mico_decompress_single_frame(in + start, end - start, px + (size_t)y0 * width, width, (int)(y1 - y0));
         if (rc) return rc;
     }
     return MICO_OK;

@@ -120,6 +120,68 @@ def pics_decompress(b: bytes):
     return rc, (out if rc == 0 else None)
 
 
+def grad_delta_rle_compress(px: np.ndarray, max_value: int) -> np.ndarray:
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w = px.shape
+    out = np.empty(4 * px.size + 16, dtype=np.uint16)
+    n = C.c_size_t()
+    rc = lib().mico_grad_delta_rle_compress(_p(px), w, h, C.c_uint16(max_value), _p(out), C.c_size_t(out.size), C.byref(n))
+    if rc:
+        raise RuntimeError(f"mico_grad_delta_rle_compress rc={rc}")
+    return out[: n.value].copy()
+
+
+def grad_delta_rle_decompress(tok: np.ndarray, w: int, h: int):
+    tok = np.ascontiguousarray(tok, dtype=np.uint16)
+    out = np.empty((h, w), dtype=np.uint16)
+    rc = lib().mico_grad_delta_rle_decompress(_p(tok), C.c_size_t(tok.size), w, h, _p(out))
+    return rc, (out if rc == 0 else None)
+
+
+def compress_single_frame_grad(px: np.ndarray, max_value: int):
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w = px.shape
+    out = np.empty(px.size * 4 + 200000, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_compress_single_frame_grad(_p(px), w, h, C.c_uint16(max_value), _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def decompress_single_frame_grad(b: bytes, w: int, h: int):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    out = np.empty((h, w), dtype=np.uint16)
+    rc = lib().mico_decompress_single_frame_grad(_p(a), C.c_size_t(a.size), _p(out), w, h)
+    return rc, (out if rc == 0 else None)
+
+
+def pica_boundaries(px: np.ndarray, num_strips: int):
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w = px.shape
+    starts = np.zeros(max(num_strips, 1), dtype=np.int32)
+    n = lib().mico_pica_boundaries(_p(px), w, h, num_strips, _p(starts))
+    return starts[:n].tolist()
+
+
+def pica_compress(px: np.ndarray, max_value: int, num_strips: int):
+    px = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w = px.shape
+    out = np.empty(px.size * 4 + 200000 * max(1, num_strips), dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_pica_compress(_p(px), w, h, C.c_uint16(max_value), num_strips, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
+def pica_decompress(b: bytes):
+    a = np.frombuffer(bytes(b), dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    rc = lib().mico_pica_decompress(_p(a), C.c_size_t(a.size), None, C.c_size_t(0), C.byref(w), C.byref(h))
+    if rc:
+        return rc, None
+    out = np.empty((h.value, w.value), dtype=np.uint16)
+    rc = lib().mico_pica_decompress(_p(a), C.c_size_t(a.size), _p(out), C.c_size_t(out.size), C.byref(w), C.byref(h))
+    return rc, (out if rc == 0 else None)
+
+
 def mic2_compress(frames: np.ndarray, max_value: int, temporal: bool = False):
     fr = np.ascontiguousarray(frames, dtype=np.uint16)
     n_, h, w = fr.shape

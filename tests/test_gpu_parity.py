@@ -568,3 +568,67 @@ def test_wavelet_v2_escape_path_full_16bit(mic, mico, synth, gpu_ready):
     assert got == want
     px, _, _ = mic.wavelet_v2_decompress(got)
     assert np.array_equal(px, img)
+
+
+# ---- gradient-adaptive predictor and PICA (deltagradrlecompressu16.go, parallelstripsadaptive.go) -------------------------
+def _pica_images(synth):
+    mr = np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
+    ct = np.fromfile(os.path.join(GOLDEN, "CT_512_512_image.bin"), dtype="<u2").reshape(512, 512)
+    xr = synth.xr_like(cols=601, rows=403, depth=12, seed=4)
+    return [("MR", mr, int(mr.max())), ("CT", ct, int(ct.max())), ("XR", xr, 4095)]
+
+
+def test_single_frame_grad_matches_oracle(mic, mico, synth, gpu_ready):
+    """CompressSingleFrameGrad / DecompressSingleFrameGrad: bit-exact streams, both directions, odd shapes and edge columns."""
+    cases = _pica_images(synth)
+    rng = np.random.default_rng(11)
+    base = cases[2][1]
+    for w, h in ((1, 64), (2, 40), (3, 33), (5, 70), (63, 65), (64, 64), (129, 130), (601, 1)):
+        cases.append((f"{w}x{h}", np.ascontiguousarray(base[:h, :w]) if w > 8 else rng.integers(1000, 1100, size=(h, w), dtype=np.uint16), 4095))
+    spikes = base.copy(); spikes[::7, ::5] = 4095; spikes[3::11, 1::9] = 0                    # escapes inside gradient neighbourhoods
+    cases.append(("spikes", spikes, 4095))
+    for name, img, mx in cases:
+        h, w = img.shape
+        rc, want = mico.compress_single_frame_grad(img, mx)
+        if rc != 0:
+            with pytest.raises(mic.MicError) as e:
+                mic.compress_single_frame_grad(img, w, h, mx)
+            assert e.value.code == rc, name
+            continue
+        got = mic.compress_single_frame_grad(img, w, h, mx)
+        assert got == want, name
+        assert np.array_equal(mic.decompress_single_frame_grad(want, w, h), img), name
+    wide = synth.xr_like(cols=9000, rows=70, depth=12, seed=6)                                  # the wide row-buffer class of the predictor kernel
+    rc, want = mico.compress_single_frame_grad(wide, 4095)
+    assert rc == 0 and mic.compress_single_frame_grad(wide, 9000, 70, 4095) == want
+    assert np.array_equal(mic.decompress_single_frame_grad(want, 9000, 70), wide)
+
+
+@pytest.mark.parametrize("strips", [1, 4, 8, 16])
+def test_pica_matches_oracle(mic, mico, synth, gpu_ready, strips):
+    for name, img, mx in _pica_images(synth):
+        h, w = img.shape
+        rc, want = mico.pica_compress(img, mx, strips)
+        if rc != 0:                                                                             # a strip neither predictor can code: same error
+            with pytest.raises(mic.MicError) as e:
+                mic.compress_parallel_strips_adaptive(img, w, h, mx, strips)
+            assert e.value.code == rc, name
+            continue
+        got = mic.compress_parallel_strips_adaptive(img, w, h, mx, strips)
+        assert got == want, name
+        assert np.array_equal(mic.decompress_parallel_strips_adaptive(want), img), name
+
+
+def test_pica_full_size_and_corrupt_headers(mic, mico, synth, gpu_ready):
+    xr = synth.xr_like(cols=2577, rows=2048, depth=12, seed=2)
+    blob = mic.compress_parallel_strips_adaptive(xr, 2577, 2048, 4095, 8)
+    assert blob[:4] == b"PICA" and np.array_equal(mic.decompress_parallel_strips_adaptive(blob), xr)
+    rc, back = mico.pica_decompress(blob)                                                      # the CPU restatement reads what the GPU wrote
+    assert rc == 0 and np.array_equal(back, xr)
+    flat = np.full((100, 37), 9, np.uint16); flat[50, 3] = 10
+    rc, want = mico.pica_compress(flat, 255, 4)
+    if rc == 0:
+        assert mic.compress_parallel_strips_adaptive(flat, 37, 100, 255, 4) == want
+    for bad in (b"PICS" + bytes(40), blob[:30], blob[:16] + bytes(16 * 8), b"PICA" + (5).to_bytes(4, "little") + (5).to_bytes(4, "little") + (0).to_bytes(4, "little")):
+        with pytest.raises(mic.MicError):
+            mic.decompress_parallel_strips_adaptive(bad)
