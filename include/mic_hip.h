@@ -58,7 +58,9 @@ const char *mic_hip_version(void);
 /* ---- unit codec: one frame / strip / plane ----------------------------------------- */
 /* Replaces CompressSingleFrame{,4State,8State} (multiframecompress.go:15,38,67) and
  * mic_compress_{two,four,eight}_state (ojph/mic_compress_c.h:26-38).
- * out_cap >= 2*width*height + 4096 is always sufficient. */
+ * out_cap >= MIC_HIP_FRAME_BOUND(width*height) is always sufficient: a frame whose every pixel escapes codes two tokens per
+ * pixel, FSE only gives up (ErrIncompressible) at two bytes per token, and the NCount header of a 65536-symbol alphabet is < 128 KiB. */
+#define MIC_HIP_FRAME_BOUND(npx) (4 * (size_t)(npx) + 135168)
 int mic_hip_compress_frame(const uint16_t *pixels, int width, int height,
                            uint16_t max_value, int nstates,
                            uint8_t *out, size_t out_cap, size_t *out_len);

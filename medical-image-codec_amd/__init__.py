@@ -178,6 +178,11 @@ def device_name() -> str:
     return lib().mic_hip_device_name().decode()
 
 
+def _frame_bound(npx: int) -> int:
+    """MIC_HIP_FRAME_BOUND (include/mic_hip.h): worst-case bytes of one coded frame / strip"""
+    return 4 * npx + 135168
+
+
 def _u16(a) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint16)
     return a
@@ -218,7 +223,7 @@ def compress_single_frame(pixels, width: int, height: int, max_value: int, nstat
     px = _u16(pixels).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "compress_single_frame")
-    cap = px.size * 2 + 4096
+    cap = _frame_bound(px.size)
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_compress_frame(px.ctypes.data, width, height, max_value, nstates, out.ctypes.data, cap, C.byref(n))
@@ -242,7 +247,7 @@ def compress_batch(frames: Sequence[np.ndarray], max_values: Sequence[int], nsta
     """One launch chain over many frames; returns [(status, blob, nstates_used)]."""
     n = len(frames)
     arrs = [_u16(f) for f in frames]
-    outs = [np.empty(a.size * 2 + 4096, dtype=np.uint8) for a in arrs]
+    outs = [np.empty(_frame_bound(a.size), dtype=np.uint8) for a in arrs]
     jobs = (EncJob * n)()
     for i, a in enumerate(arrs):
         h, w = a.shape
@@ -276,7 +281,7 @@ def compress_parallel_strips(pixels, width: int, height: int, max_value: int, nu
     px = _u16(pixels).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "parallelstrips: pixel count != width*height")
-    cap = px.size * 2 + 4096 * (max(num_strips, 1) + 1) + 8 * max(num_strips, 1) + 20
+    cap = px.size * 4 + 135168 * max(num_strips, 1) + 8 * max(num_strips, 1) + 20
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_pics_compress(px.ctypes.data, width, height, max_value, num_strips, nstates, out.ctypes.data, cap, C.byref(n))
@@ -311,7 +316,7 @@ def compress_multi_frame(frames: np.ndarray, width: int, height: int, max_value:
     (frame 0 spatial, ZigZag residuals of consecutive frames after it)."""
     fr = _u16(frames)
     nframes = fr.shape[0]
-    cap = fr.size * 2 + 4096 * (nframes + 1) + 8 * nframes + 20
+    cap = fr.size * 4 + 135168 * nframes + 8 * nframes + 20
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     fn = lib().mic_hip_mic2_compress_temporal if temporal else lib().mic_hip_mic2_compress
@@ -475,7 +480,7 @@ def compress_single_frame_grad(pixels, width: int, height: int, max_value: int) 
     px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "compress_single_frame_grad")
-    cap = px.size * 2 + 8192
+    cap = _frame_bound(px.size)
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_compress_frame_grad(px.ctypes.data, width, height, max_value, out.ctypes.data, cap, C.byref(n))
@@ -499,7 +504,7 @@ def compress_parallel_strips_adaptive(pixels, width: int, height: int, max_value
     px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "compress_parallel_strips_adaptive")
-    cap = px.size * 2 + 8192 * max(1, num_strips) + 4096
+    cap = px.size * 4 + 135168 * max(1, num_strips) + 16 * max(1, num_strips) + 16
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_pica_compress(px.ctypes.data, width, height, max_value, num_strips, out.ctypes.data, cap, C.byref(n))
@@ -562,7 +567,7 @@ def write_mic1(pixels, width: int, height: int, max_value: int, nstates: int = 2
     px = np.ascontiguousarray(pixels, dtype=np.uint16).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "write_mic1")
-    cap = px.size * 2 + 8192
+    cap = _frame_bound(px.size) + 20
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_mic1_compress(px.ctypes.data, width, height, max_value, nstates, out.ctypes.data, cap, C.byref(n))

@@ -406,7 +406,7 @@ int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_
         j = mic_hip_enc_job{};
         j.pixels = pixels + (size_t)y0 * (size_t)width; j.width = width; j.height = y1 - y0;
         j.max_value = max_value; j.nstates = (uint16_t)nstates;       // global maxValue for every strip, :88
-        bufs[(size_t)s].resize((size_t)width * (size_t)(y1 - y0) * 2 + 4096);
+        bufs[(size_t)s].resize(MIC_HIP_FRAME_BOUND((size_t)width * (size_t)(y1 - y0)));
         j.out = bufs[(size_t)s].data(); j.out_cap = bufs[(size_t)s].size();
     }
     int rc = mic_hip_compress_batch(jobs.data(), actual);
@@ -475,12 +475,13 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     size_t header = 20 + (size_t)nframes * 8;
     if (out_cap < header) return MIC_ERR_CAPACITY;
     std::vector<mic_hip_enc_job> jobs((size_t)nframes);
-    std::vector<uint8_t> buf((npx * 2 + 4096) * (size_t)nframes);
+    const size_t fcap = MIC_HIP_FRAME_BOUND(npx);
+    std::vector<uint8_t> buf(fcap * (size_t)nframes);
     for (int i = 0; i < nframes; i++) {
         mic_hip_enc_job &j = jobs[(size_t)i];
         j = mic_hip_enc_job{};
         j.pixels = frames + npx * (size_t)i; j.width = width; j.height = height; j.max_value = max_value; j.nstates = 2;
-        j.out = buf.data() + (npx * 2 + 4096) * (size_t)i; j.out_cap = npx * 2 + 4096;
+        j.out = buf.data() + fcap * (size_t)i; j.out_cap = fcap;
     }
     int rc = mic_hip_compress_batch(jobs.data(), nframes);
     if (rc) return rc;

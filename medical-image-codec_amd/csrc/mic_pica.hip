@@ -149,26 +149,35 @@ int mic_hip_pica_compress(const uint16_t *pixels, int width, int height, uint16_
             max_px = mp; s1++;
         }
         const int ns = s1 - s0;
-        std::vector<mic_hip_unit> units((size_t)ns * 2);
+        // a strip of no rows (the partition clamps late boundaries to the last row, :282-284) has nothing to code: the unit codec
+        // rejects it like the oracle does, in strip order with the other strips' errors
+        std::vector<mic_hip_unit> units; std::vector<int> slot((size_t)ns, -1);
         for (int k = 0; k < ns; k++) {
             const int y0 = starts[(size_t)(s0 + k)], y1 = (s0 + k + 1 < actual) ? starts[(size_t)(s0 + k) + 1] : height;
-            units[(size_t)k * 2] = mic_hip_unit{ (uint64_t)y0 * (uint64_t)width, width, y1 - y0, max_value, 2 };                          // :92
-            units[(size_t)k * 2 + 1] = mic_hip_unit{ (uint64_t)y0 * (uint64_t)width, width, y1 - y0, max_value, (uint16_t)(2 | MIC_HIP_PRED_GRAD) };   // :94
+            if (y1 <= y0) continue;
+            slot[(size_t)k] = (int)units.size();
+            units.push_back(mic_hip_unit{ (uint64_t)y0 * (uint64_t)width, width, y1 - y0, max_value, 2 });                                          // :92
+            units.push_back(mic_hip_unit{ (uint64_t)y0 * (uint64_t)width, width, y1 - y0, max_value, (uint16_t)(2 | MIC_HIP_PRED_GRAD) });         // :94
         }
-        if ((rc = session_encode_enqueue(s, (const uint16_t *)s->io_px.p, units.data(), ns * 2))) return rc;
-        std::vector<uint64_t> offs((size_t)ns * 2 + 1); std::vector<int32_t> st((size_t)ns * 2), nst((size_t)ns * 2);
+        const int nu = (int)units.size();
+        std::vector<uint64_t> offs((size_t)nu + 1, 0); std::vector<int32_t> st((size_t)nu), nst((size_t)nu);
         const uint8_t *d_blobs = nullptr;
-        if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), nst.data()))) return rc;
+        if (nu) {
+            if ((rc = session_encode_enqueue(s, (const uint16_t *)s->io_px.p, units.data(), nu))) return rc;
+            if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), nst.data()))) return rc;
+        }
         for (int k = 0; k < ns; k++) {
-            const int32_t e1 = st[(size_t)k * 2], e2 = st[(size_t)k * 2 + 1];
-            const size_t la = (size_t)(offs[(size_t)k * 2 + 1] - offs[(size_t)k * 2]), lg = (size_t)(offs[(size_t)k * 2 + 2] - offs[(size_t)k * 2 + 1]);
+            if (slot[(size_t)k] < 0) return MIC_ERR_ARGS;
+            const size_t a = (size_t)slot[(size_t)k];
+            const int32_t e1 = st[a], e2 = st[a + 1];
+            const size_t la = (size_t)(offs[a + 1] - offs[a]), lg = (size_t)(offs[a + 2] - offs[a + 1]);
             int pick;
             if (e2 == MIC_OK && (e1 != MIC_OK || lg <= la)) pick = 1;                          // the smaller, or the one that succeeded (:97-105)
             else { pick = 0; if (e1 != MIC_OK) return e1; }                                    // "pica: strip %d: ..." (:110-114)
             const size_t len = pick ? lg : la;
             blob[(size_t)(s0 + k)].resize(len);
             flags[(size_t)(s0 + k)] = pick ? 1u : 0u;
-            if (len) HIP_TRY(hipMemcpy(blob[(size_t)(s0 + k)].data(), d_blobs + offs[(size_t)k * 2 + (size_t)pick], len, hipMemcpyDeviceToHost));
+            if (len) HIP_TRY(hipMemcpy(blob[(size_t)(s0 + k)].data(), d_blobs + offs[a + (size_t)pick], len, hipMemcpyDeviceToHost));
         }
         s0 = s1;
     }

@@ -77,7 +77,7 @@ struct mic_hip_session {
         tok_stride = align_up(tok_cap_for(pp) * 2, 256);
         blob_stride = align_up(blob_cap_for(pp), 256);
         seg_stride = align_up((2 * pp + 8) * 8, 256);
-        sym_stride = align_up(tok_cap_for(pp) * 2, 256);
+        sym_stride = align_up((tok_cap_for(pp) + 64) * 2, 256);   // + a block: the tANS encoder rounds its per-token states up to 32
         flag_stride = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
         int rc;
         if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
@@ -112,7 +112,7 @@ struct mic_hip_session {
         u.seg = (uint2 *)((char *)seg.p + seg_stride * (size_t)i);
         u.seg_cap = (uint32_t)std::min<size_t>(2 * max_px + 8, 0xFFFFFFF0u);
         u.sym = (uint16_t *)((char *)sym.p + sym_stride * (size_t)i);
-        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
+        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px) + 64, 0xFFFFFFF0u);
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     void release() {

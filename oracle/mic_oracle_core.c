@@ -1153,7 +1153,7 @@ int mico_pica_compress(const uint16_t *px, int w, int h, uint16_t max_value, int
     int actual = mico_pica_boundaries(px, w, h, num_strips, starts);
     if (actual < 0) { free(starts); return actual; }
     size_t header = 16 + (size_t)actual * 16;
-    size_t scap = 4 * (size_t)w * (size_t)h + 4096;
+    size_t scap = 4 * (size_t)w * (size_t)h + 262144;             /* room for the worst-case NCount header: no capacity errors of our own */
     uint8_t *ba = (uint8_t *)malloc(scap), *bg = (uint8_t *)malloc(scap);
     int rc = (ba && bg) ? MICO_OK : MICO_ERR_NOMEM;
     if (rc == MICO_OK && cap < header) rc = MICO_ERR_CAPACITY;
