@@ -360,7 +360,7 @@ def wavelet_v2_compress(pixels, rows: int, cols: int, max_value: int, levels: in
     px = _u16(pixels).reshape(-1)
     if px.size != rows * cols:
         raise MicError(MIC_ERR_ARGS, "pixel count does not match rows*cols")
-    cap = px.size * 2 + 200000
+    cap = px.size * 6 + 200000
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     rc = lib().mic_hip_wavelet_v2_compress(px.ctypes.data, rows, cols, max_value, levels, out.ctypes.data, cap, C.byref(n))

@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
     u.max_count = s_max[0]; u.symbol_len = s_len[0];
     // Gate order of FSECompressU16* (fse2state.go:23-42); the length gate depends on the
     // flavour and is applied per attempt in k_enc_tans.
-    if (n <= 1) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
+    if (n <= 1 || (u.no_fallback && n <= (u.nstates == 108 ? 8u : (uint32_t)u.nstates) - 1)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
     if (u.max_count == n) { u.status = MICD_ERR_USE_RLE; return; }
     if (u.max_count == 1 || u.max_count < (n >> 15)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
     u.table_log = mic_optimal_table_log(n, u.symbol_len);

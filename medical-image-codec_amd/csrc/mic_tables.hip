@@ -424,7 +424,9 @@ __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
         u.max_count = mm; u.symbol_len = ss;
         int rc = MICD_OK;
         // gate order of FSECompressU16* (fse2state.go:23-42); the flavour's length gate is applied in k_enc_tans_wg
-        if (n <= 1) rc = MICD_ERR_INCOMPRESSIBLE;
+        // (a bare FSE call has no fallback chain: its own flavour's length gate comes before the histogram gates, fse8state.go:32-34)
+        const uint32_t lanes0 = u.nstates == 108 ? 8u : (uint32_t)u.nstates;
+        if (n <= 1 || (u.no_fallback && n <= lanes0 - 1)) rc = MICD_ERR_INCOMPRESSIBLE;
         else if (mm == n) rc = MICD_ERR_USE_RLE;
         else if (mm == 1 || mm < (n >> 15)) rc = MICD_ERR_INCOMPRESSIBLE;
         uint32_t tl = 0;

@@ -51,8 +51,8 @@ while time.time() - t0 < budget:
     h = int(rng.choice([1, 2, 5, 17, 64, 65, 130, int(rng.integers(1, 300))]))
     depth = int(rng.integers(4, 17))
     img, mv, kind = content(w, h, depth)
-    mode = int(rng.integers(0, 5)); ns = int(rng.choice([2, 4, 8]))
-    key = ("frame", "grad", "pics", "pica", "mic2")[mode]
+    mode = int(rng.integers(0, 9)); ns = int(rng.choice([2, 4, 8]))
+    key = ("frame", "grad", "pics", "pica", "mic2", "fse", "wavelet", "wsi", "rgb")[mode]
     try:
         if mode == 0:
             rc, want = mico.compress_single_frame(img, mv, ns)
@@ -84,6 +84,49 @@ while time.time() - t0 < budget:
             except mic.MicError as e: got_rc = e.code
             if not same_rc(rc, got_rc) or (rc == 0 and got != want): fail("pica", img, mv, (strips, rc, got_rc, kind))
             if rc == 0 and not np.array_equal(mic.decompress_parallel_strips_adaptive(want), img): fail("pica decode", img, mv, (strips, kind))
+        elif mode == 5:                                                      # bare FSE stage on the frame's token stream or on raw symbols
+            sym = mico.delta_rle_compress(img, mv) if rng.random() < 0.5 else img.reshape(-1)
+            fl = int(rng.choice([1, 2, 4, 8]))
+            rc, want = mico.fse_compress(sym, fl)
+            got_rc, got = 0, None
+            try: got = mic.fse_compress_u16(sym, fl)
+            except mic.MicError as e: got_rc = e.code
+            if not same_rc(rc, got_rc) or (rc == 0 and got != want): fail("fse", img, mv, (fl, rc, got_rc, kind))
+            if rc == 0 and not np.array_equal(mic.fse_decompress_u16_auto(want, sym.size), sym): fail("fse decode", img, mv, (fl, kind))
+        elif mode == 6:
+            if w < 2 or h < 2: continue
+            lv = int(rng.integers(1, 6))
+            rc, want = mico.wavelet_v2_compress(img, mv, lv)
+            got_rc, got = 0, None
+            try: got = mic.wavelet_v2_compress(img, h, w, mv, lv)
+            except mic.MicError as e: got_rc = e.code
+            if not same_rc(rc, got_rc) or (rc == 0 and got != want): fail("wavelet", img, mv, (lv, rc, got_rc, kind))
+            if rc == 0 and not np.array_equal(mic.wavelet_v2_decompress(want)[0].reshape(h, w), img): fail("wavelet decode", img, mv, (lv, kind))
+        elif mode == 7:
+            grey = rng.random() < 0.5
+            tw, th = int(rng.choice([16, 32, 64, 100])), int(rng.choice([16, 32, 64, 100]))
+            if grey:
+                src = img if depth > 8 else img.astype(np.uint8)
+                rc, want = mico.wsi_compress_grey(src, tw, th, 0)
+                got_rc, got = 0, None
+                try: got = mic.compress_wsi(src, w, h, channels=1, bits_per_sample=16 if src.dtype == np.uint16 else 8, tile_w=tw, tile_h=th)
+                except mic.MicError as e: got_rc = e.code
+            else:
+                src = np.stack([(img >> k).astype(np.uint8) for k in (0, 2, 4)], axis=-1)
+                rc, want = mico.wsi_compress(src, tw, th, 0)
+                got_rc, got = 0, None
+                try: got = mic.compress_wsi(src, w, h, tile_w=tw, tile_h=th)
+                except mic.MicError as e: got_rc = e.code
+            if not same_rc(rc, got_rc) or (rc == 0 and got != want): fail("wsi", img, mv, (grey, tw, th, rc, got_rc, kind))
+            if rc == 0 and not np.array_equal(mic.decompress_wsi_level(want, 0), src): fail("wsi decode", img, mv, (grey, tw, th, kind))
+        elif mode == 8:
+            src = np.ascontiguousarray(np.stack([(img >> k).astype(np.uint8) for k in (0, 3, 5)], axis=-1))
+            rc, want = mico.wsi_compress_tile(src)
+            got_rc, got = 0, None
+            try: got = mic.compress_rgb(src, w, h)
+            except mic.MicError as e: got_rc = e.code
+            if not same_rc(rc, got_rc) or (rc == 0 and got != want): fail("rgb", img, mv, (rc, got_rc, kind))
+            if rc == 0 and not np.array_equal(mic.decompress_rgb(want, w, h), src): fail("rgb decode", img, mv, (kind,))
         else:
             nf = int(rng.integers(1, 6)); temporal = bool(rng.integers(0, 2))
             stack = np.stack([np.clip(img.astype(np.int64) + rng.integers(-2, 3, size=img.shape) * (k > 0), 0, 65535).astype(np.uint16) for k in range(nf)])
