@@ -28,6 +28,7 @@ MIC_ERR_CORRUPT = -6
 MIC_ERR_DEVICE = -7
 MIC_ERR_INTERNAL = -8
 MIC_ERR_UNSUPPORTED = -9
+MIC_HIP_PRED_GRAD = 0x200          # OR'ed into a session unit's nstates: gradient-adaptive predictor (include/mic_hip.h)
 MIC_ERR_INCOMPRESSIBLE = -10
 
 _ERR_NAMES = {

@@ -632,3 +632,42 @@ def test_pica_full_size_and_corrupt_headers(mic, mico, synth, gpu_ready):
     for bad in (b"PICS" + bytes(40), blob[:30], blob[:16] + bytes(16 * 8), b"PICA" + (5).to_bytes(4, "little") + (5).to_bytes(4, "little") + (0).to_bytes(4, "little")):
         with pytest.raises(mic.MicError):
             mic.decompress_parallel_strips_adaptive(bad)
+
+
+# ---- device-resident sessions (what bench.py times): pixels in HBM, blobs in HBM ---------------------------------------------
+def test_session_device_resident_units(mic, mico, synth, gpu_ready):
+    """mic_hip_session_*: ragged units of one HBM buffer, both predictors and all state counts in ONE batch; every blob equals the
+    oracle's for that unit, and the decode of the packed device blobs restores the buffer."""
+    torch = pytest.importorskip("torch")
+    W = 333
+    img = synth.xr_like(cols=W, rows=400, depth=12, seed=21)
+    specs = [(0, 64, 2), (64, 37, 4), (101, 1, 2), (102, 130, 8), (232, 100, 2 | mic.MIC_HIP_PRED_GRAD), (332, 68, 2 | mic.MIC_HIP_PRED_GRAD)]
+    units = mic.Session.make_units([(y0 * W, W, hh, 4095, ns) for (y0, hh, ns) in specs])
+    d_px = torch.from_numpy(img.view(np.int16).copy()).cuda()
+    d_out = torch.zeros_like(d_px)
+    sess = mic.Session(len(specs), W * 130)
+    try:
+        sess.encode_enqueue(d_px.data_ptr(), units)
+        d_blobs, offs, st, used = sess.encode_finish()
+        total = int(offs[-1])
+        import ctypes as C
+        host = np.empty(total, np.uint8)
+        assert C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(d_blobs), C.c_size_t(total), 2) == 0   # D2H
+        for k, (y0, hh, ns) in enumerate(specs):
+            sub = img[y0: y0 + hh]
+            rc, want = (mico.compress_single_frame_grad(sub, 4095) if ns & mic.MIC_HIP_PRED_GRAD else mico.compress_single_frame(sub, 4095, ns & 0xFF))
+            assert st[k] == rc, (k, st[k], rc)
+            if rc == 0:
+                assert host[int(offs[k]): int(offs[k + 1])].tobytes() == want, k
+        ok = [k for k in range(len(specs)) if st[k] == 0]
+        assert len(ok) >= 4
+        sess.decode_enqueue(d_blobs, offs, units, d_out.data_ptr())
+        dst = sess.decode_finish()
+        back = d_out.cpu().numpy().view(np.uint16)
+        for k, (y0, hh, ns) in enumerate(specs):
+            if st[k] == 0:
+                assert dst[k] == 0 and np.array_equal(back[y0: y0 + hh], img[y0: y0 + hh]), k
+        with pytest.raises(mic.MicError):                                        # an unknown flag in nstates
+            sess.encode_enqueue(d_px.data_ptr(), mic.Session.make_units([(0, W, 8, 4095, 2 | 0x400)]))
+    finally:
+        sess.close()
