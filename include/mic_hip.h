@@ -179,6 +179,17 @@ int mic_hip_wavelet_v2_info(const uint8_t *compressed, size_t compressed_len,
 int mic_hip_wavelet_v2_decompress(const uint8_t *compressed, size_t compressed_len,
                                   uint16_t *pixels_out, size_t out_cap_px);
 
+/* Many frames of one shape side by side (the reference codes one image per call; a WaveletV2 file is ONE serial 4-state FSE
+ * stream, so a single decode is one wave walking one chain -- the device pays off when frames are coded together).
+ * compress_batch: frames = nframes x rows*cols u16, contiguous; frame i's file (byte-identical to the single call's) is written at
+ * out + i*out_stride, out_lens[i] / status[i] per frame; a failing frame does not stop the others.
+ * decompress_batch: nframes files of ONE shape (rows, cols, levels of files[0]; others: status MIC_ERR_ARGS); pixels_out receives
+ * nframes x rows*cols u16. */
+int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int rows, int cols, uint16_t max_value, int levels,
+                                      uint8_t *out, size_t out_stride, size_t *out_lens, int32_t *status);
+int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_t *lens, int nframes,
+                                        uint16_t *pixels_out, size_t out_cap_px, int32_t *status);
+
 /* ---- MIC3 container: tiled RGB whole-slide images ---------------------------------------------- */
 /* Replaces CompressWSI (wsicompress.go:27) + WriteMIC3 (wsiformat.go:99) for 8-bit RGB with the
  * YCoCg-R colour transform (forced on for RGB, wsiformat.go:93-95).  tile_w / tile_h = 0 select the

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
-    "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
+    "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_compress_batch", "mic_hip_wavelet_v2_decompress_batch", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
     "mic_hip_compress_frame_grad", "mic_hip_decompress_frame_grad", "mic_hip_pica_compress", "mic_hip_pica_info", "mic_hip_pica_decompress",
     "mic_hip_rgb_compress", "mic_hip_rgb_decompress", "mic_hip_micr_compress", "mic_hip_micr_info", "mic_hip_micr_decompress",
     "mic_hip_mic1_compress", "mic_hip_mic1_info", "mic_hip_mic1_decompress",
@@ -139,6 +139,9 @@ def lib() -> C.CDLL:
     L.mic_hip_mic2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_mic2_decompress_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
     L.mic_hip_wavelet_v2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_wavelet_v2_compress_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_void_p, C.c_size_t,
+                                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    L.mic_hip_wavelet_v2_decompress_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)]
     L.mic_hip_wavelet_v2_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_wavelet_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.mic_hip_wsi_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -368,6 +371,35 @@ def wavelet_v2_compress(pixels, rows: int, cols: int, max_value: int, levels: in
     if rc:
         _raise(rc, "wavelet_v2_compress")
     return out[: n.value].tobytes()
+
+
+def wavelet_v2_compress_batch(frames, max_value: int, levels: int = 5) -> List[Tuple[int, bytes]]:
+    """nframes x rows x cols frames of one shape in one launch chain: [(status, file)], each file as the single call writes it."""
+    fr = np.ascontiguousarray(frames, dtype=np.uint16)
+    nf, rows, cols = fr.shape
+    stride = rows * cols * 6 + 200000
+    out = np.empty(nf * stride, dtype=np.uint8)
+    lens = (C.c_size_t * nf)(); st = (C.c_int32 * nf)()
+    rc = lib().mic_hip_wavelet_v2_compress_batch(fr.ctypes.data, nf, rows, cols, max_value, levels, out.ctypes.data, stride, lens, st)
+    if rc:
+        _raise(rc, "wavelet_v2_compress_batch")
+    return [(int(st[i]), out[i * stride: i * stride + lens[i]].tobytes() if st[i] == 0 else b"") for i in range(nf)]
+
+
+def wavelet_v2_decompress_batch(files: Sequence[bytes]) -> Tuple[List[int], np.ndarray]:
+    """files of ONE shape -> ([status], nframes x rows x cols uint16)."""
+    cs = [_bytes_arr(b) for b in files]
+    nf = len(cs)
+    r, cc, mv, lv = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().mic_hip_wavelet_v2_info(cs[0].ctypes.data, cs[0].size, C.byref(r), C.byref(cc), C.byref(mv), C.byref(lv))
+    if rc:
+        _raise(rc, "wavelet_v2_decompress_batch")
+    out = np.zeros((nf, max(r.value, 0), max(cc.value, 0)), dtype=np.uint16)
+    ptrs = (C.c_void_p * nf)(*[c.ctypes.data for c in cs]); lens = (C.c_size_t * nf)(*[c.size for c in cs]); st = (C.c_int32 * nf)()
+    rc = lib().mic_hip_wavelet_v2_decompress_batch(ptrs, lens, nf, out.ctypes.data, out.size, st)
+    if rc:
+        _raise(rc, "wavelet_v2_decompress_batch")
+    return [int(v) for v in st], out
 
 
 def wavelet_v2_decompress(compressed) -> Tuple[np.ndarray, int, int]:

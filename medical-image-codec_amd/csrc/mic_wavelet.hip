@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) k_wv_store(const int32_t *a, uint16_t *px
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) px[i] = (uint16_t)a[i];
 }
 // rows of the r x c region: src -> dst, de-interleaved [low | high]   (waveletu16.go:170-182)
-__global__ void __launch_bounds__(256) k_wv_fwd_rows(const int32_t *src, int32_t *dst, int r, int c, int stride) {
+__global__ void __launch_bounds__(256) k_wv_fwd_rows(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
+    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
     const size_t n = (size_t)r * c; const int n_low = (c + 1) / 2;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(t / c), k = (int)(t % c);
@@ -78,7 +79,8 @@ __global__ void __launch_bounds__(256) k_wv_fwd_rows(const int32_t *src, int32_t
     }
 }
 // columns of the r x c region   (waveletu16.go:183-208)
-__global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *src, int32_t *dst, int r, int c, int stride) {
+__global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
+    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
     const size_t n = (size_t)r * c; const int n_low = (r + 1) / 2;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(t / c), xcol = (int)(t % c);
@@ -87,7 +89,8 @@ __global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *src, int32_t
     }
 }
 // inverse: columns first, then rows   (waveletu16.go:213-257)
-__global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *src, int32_t *dst, int r, int c, int stride) {
+__global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
+    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
     const size_t n = (size_t)r * c;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(t / c), xcol = (int)(t % c);
@@ -95,7 +98,8 @@ __global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *src, int32_t
         dst[(size_t)k * stride + xcol] = wv_sample(cf, r, k);
     }
 }
-__global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *src, int32_t *dst, int r, int c, int stride) {
+__global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
+    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
     const size_t n = (size_t)r * c;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(t / c), k = (int)(t % c);
@@ -137,7 +141,8 @@ __device__ __forceinline__ uint32_t wv_wave_incl(uint32_t v, uint32_t lane) {
 // subband scan + waveletCoeffsToU16 (:28-40) + zzMax (:335-349).  One work-group per image; writes the
 // symbol stream into u.sym, its length into u.nsym and the RLE maxValue into u.max_value.
 __global__ void __launch_bounds__(WV_THREADS) k_wv_symbols(MicUnit *units, const int32_t *a, WvDims d) {
-    MicUnit &u = units[0];
+    MicUnit &u = units[blockIdx.x];
+    a += (size_t)blockIdx.x * (size_t)d.rows * (size_t)d.cols;             // one group per frame of the batch
     __shared__ uint32_t s_scan[WV_WAVES], s_max[WV_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t n = (size_t)d.rows * d.cols;
@@ -249,7 +254,8 @@ __device__ __forceinline__ uint32_t wv_fn_compose(uint32_t g, uint32_t f) {     
     return ((g >> (2 * f0)) & 3) | (((g >> (2 * f1)) & 3) << 2) | (((g >> (2 * f2)) & 3) << 4);
 }
 __global__ void __launch_bounds__(WV_THREADS) k_wv_coeffs(MicUnit *units, int32_t *a, WvDims d) {
-    MicUnit &u = units[0];
+    MicUnit &u = units[blockIdx.x];
+    a += (size_t)blockIdx.x * (size_t)d.rows * (size_t)d.cols;
     if (u.status != MICD_OK) return;
     __shared__ uint32_t s_scan[WV_WAVES], s_fn[WV_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,15 +309,104 @@ void mic_launch_rle_expand(MicUnit *d_units, int n, hipStream_t stream, int mode
     hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)n), dim3(WV_THREADS), 0, stream, d_units, mode_filter);
 }
 
+namespace {
+
+// nf frames of rows x cols, contiguous on the device in s->io_px: forward transform, symbols, RLE + 4-state FSE in one batch.
+// blobs[i] receives frame i's FSE stream (without the 11-byte header), st[i] its status.
+int wv_compress_frames(mic_hip_session *s, int nf, int rows, int cols, int applied, std::vector<std::vector<uint8_t>> &blobs, std::vector<int32_t> &st) {
+    const size_t n = (size_t)rows * (size_t)cols;
+    int rc;
+    if ((rc = s->ensure(nf, 2 * n + 16))) return rc;                     // room for 3-word escapes
+    DevBuf a, b;
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) { a.release(); b.release(); return rc; }
+    auto done = [&](int code) { a.release(); b.release(); return code; };
+    int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
+    hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const uint16_t *)s->io_px.p, A, n * (size_t)nf);
+    { int r = rows, c = cols;
+      for (int l = 0; l < applied; l++) {
+          hipLaunchKernelGGL(k_wv_fwd_rows, dim3(grid_for((size_t)r * c), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, c, cols, n);
+          hipLaunchKernelGGL(k_wv_fwd_cols, dim3(grid_for((size_t)r * c), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n);
+          r = (r + 1) / 2; c = (c + 1) / 2;
+      } }
+    s->h_units.assign((size_t)nf, MicUnit{});
+    for (int i = 0; i < nf; i++) {
+        MicUnit &u = s->h_units[(size_t)i];
+        u.w = 1; u.h = 1; u.nstates = 4; u.mode = 2; u.no_fallback = 1; // FSECompressU16FourState, no fallback (:344)
+        s->fill_workspace(u, i);
+    }
+    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    if (hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    hipLaunchKernelGGL(k_wv_symbols, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, wv_dims(rows, cols, applied));
+    mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr);
+    if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
+    s->n_last = nf;
+    std::vector<uint64_t> offs((size_t)nf + 1); std::vector<int32_t> ns((size_t)nf); const uint8_t *d_blobs = nullptr;
+    st.assign((size_t)nf, 0);
+    if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data()))) return done(rc);
+    std::vector<uint8_t> host((size_t)offs[(size_t)nf] + 16);
+    if (offs[(size_t)nf] && hipMemcpy(host.data(), d_blobs, (size_t)offs[(size_t)nf], hipMemcpyDeviceToHost) != hipSuccess) return done(MIC_ERR_DEVICE);
+    blobs.assign((size_t)nf, std::vector<uint8_t>());
+    for (int i = 0; i < nf; i++) if (st[(size_t)i] == MIC_OK) blobs[(size_t)i].assign(host.begin() + (long)offs[(size_t)i], host.begin() + (long)offs[(size_t)i + 1]);
+    return done(MIC_OK);
+}
+
+// nf FSE streams (already in s->io_comp at offs[i] .. offs[i + 1]) of frames of one shape -> pixels in s->io_px
+int wv_decompress_frames(mic_hip_session *s, int nf, const std::vector<uint64_t> &offs, int rows, int cols, int levels, std::vector<int32_t> &st) {
+    const size_t n = (size_t)rows * (size_t)cols;
+    int rc;
+    if ((rc = s->ensure(nf, 2 * n + 16))) return rc;
+    DevBuf a, b;
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) { a.release(); b.release(); return rc; }
+    auto done = [&](int code) { a.release(); b.release(); return code; };
+    s->h_units.assign((size_t)nf, MicUnit{});
+    for (int i = 0; i < nf; i++) {
+        MicUnit &u = s->h_units[(size_t)i];
+        u.comp_in = (const uint8_t *)s->io_comp.p + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1;
+        s->fill_workspace(u, i);
+    }
+    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
+    if (hipMemsetAsync(A, 0, n * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr);
+    const WvDims d = wv_dims(rows, cols, levels);
+    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
+    hipLaunchKernelGGL(k_wv_coeffs, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
+    for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
+        const int r = d.nr[l], cc = d.nc[l];
+        hipLaunchKernelGGL(k_wv_inv_cols, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n);
+        hipLaunchKernelGGL(k_wv_inv_rows, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, cc, cols, n);
+    }
+    hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, (uint16_t *)s->io_px.p, n * (size_t)nf);
+    if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
+    s->n_last = nf;
+    st.assign((size_t)nf, 0);
+    if ((rc = session_decode_finish(s, st.data()))) return done(rc);
+    return done(MIC_OK);
+}
+
+void wv_put_header(uint8_t *out, int rows, int cols, uint16_t max_value, int applied) {     // :346-350
+    out[0] = (uint8_t)rows; out[1] = (uint8_t)(rows >> 8); out[2] = (uint8_t)(rows >> 16); out[3] = (uint8_t)((uint32_t)rows >> 24);
+    out[4] = (uint8_t)cols; out[5] = (uint8_t)(cols >> 8); out[6] = (uint8_t)(cols >> 16); out[7] = (uint8_t)((uint32_t)cols >> 24);
+    out[8] = (uint8_t)max_value; out[9] = (uint8_t)(max_value >> 8);
+    out[10] = (uint8_t)applied;
+}
+
+size_t wv_frames_per_batch(size_t n) { return std::max<size_t>(1, kWorkspaceBudget / (unit_ws_bytes(2 * n + 16) + 8 * n)); }
+
+}  // namespace
+
 extern "C" {
 
-// WaveletV2RLEFSECompressU16 / WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303, :374)
-int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint16_t max_value, int levels,
-                                uint8_t *out, size_t out_cap, size_t *out_len) {
-    if (!pixels || !out || !out_len || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
+// WaveletV2RLEFSECompressU16 over nframes frames of one shape in one launch chain (the reference codes one image per call; a
+// WaveletV2 file is ONE serial FSE stream, so the GPU only pays off when many frames are coded side by side).
+// frames: nframes x rows*cols u16, contiguous.  Frame i's file goes to out + i * out_stride, its length to out_lens[i], its
+// status to status[i] (a frame that fails does not stop the others).
+int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int rows, int cols, uint16_t max_value, int levels,
+                                      uint8_t *out, size_t out_stride, size_t *out_lens, int32_t *status) {
+    if (!frames || !out || !out_lens || !status || nframes <= 0 || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
     const size_t n = (size_t)rows * (size_t)cols;
     if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
-    if (out_cap < 11) return MIC_ERR_CAPACITY;
+    if (out_stride < 11) return MIC_ERR_CAPACITY;
     if (levels < 1) levels = 1;
     if (levels > 8) levels = 8;
     int applied = 0;
@@ -320,42 +415,38 @@ int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint
     int rc = ensure_device();
     if (rc) return rc;
     mic_hip_session *s = &g_default;
-    if ((rc = s->ensure(1, 2 * n + 16))) return rc;                      // room for 3-word escapes
-    if ((rc = s->io_px.reserve(n * 2 + 64))) return rc;
-    DevBuf a, b;
-    if ((rc = a.reserve(n * 4 + 64)) || (rc = b.reserve(n * 4 + 64))) { a.release(); b.release(); return rc; }
-    auto done = [&](int code) { a.release(); b.release(); return code; };
-    if (hipMemcpyAsync(s->io_px.p, pixels, n * 2, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
-    hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n)), dim3(256), 0, s->stream, (const uint16_t *)s->io_px.p, A, n);
-    { int r = rows, c = cols;
-      for (int l = 0; l < applied; l++) {
-          hipLaunchKernelGGL(k_wv_fwd_rows, dim3(grid_for((size_t)r * c)), dim3(256), 0, s->stream, (const int32_t *)A, B, r, c, cols);
-          hipLaunchKernelGGL(k_wv_fwd_cols, dim3(grid_for((size_t)r * c)), dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols);
-          r = (r + 1) / 2; c = (c + 1) / 2;
-      } }
-    s->h_units.assign(1, MicUnit{});
-    MicUnit &u = s->h_units[0];
-    u.w = 1; u.h = 1; u.nstates = 4; u.mode = 2; u.no_fallback = 1;     // FSECompressU16FourState, no fallback (:344)
-    s->fill_workspace(u, 0);
-    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    if (hipMemsetAsync(s->hist.p, 0, kSym * 4, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    hipLaunchKernelGGL(k_wv_symbols, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, wv_dims(rows, cols, applied));
-    mic_launch_encode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
-    if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
-    s->n_last = 1;
-    uint64_t offs[2]; int32_t st = 0, ns = 0; const uint8_t *d_blobs = nullptr;
-    if ((rc = session_encode_finish(s, &d_blobs, offs, &st, &ns))) return done(rc);
-    if (st != MIC_OK) return done(st);
-    const size_t len = (size_t)offs[1];
-    if (11 + len > out_cap) return done(MIC_ERR_CAPACITY);
-    if (hipMemcpy(out + 11, d_blobs, len, hipMemcpyDeviceToHost) != hipSuccess) return done(MIC_ERR_DEVICE);
-    out[0] = (uint8_t)rows; out[1] = (uint8_t)(rows >> 8); out[2] = (uint8_t)(rows >> 16); out[3] = (uint8_t)((uint32_t)rows >> 24);   // :346-350
-    out[4] = (uint8_t)cols; out[5] = (uint8_t)(cols >> 8); out[6] = (uint8_t)(cols >> 16); out[7] = (uint8_t)((uint32_t)cols >> 24);
-    out[8] = (uint8_t)max_value; out[9] = (uint8_t)(max_value >> 8);
-    out[10] = (uint8_t)applied;
-    *out_len = 11 + len;
-    return done(MIC_OK);
+    const size_t per = wv_frames_per_batch(n);
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += per) {
+        const int nf = (int)std::min(per, (size_t)nframes - f0);
+        if ((rc = s->ensure(nf, 2 * n + 16))) return rc;
+        if ((rc = s->io_px.reserve(n * 2 * (size_t)nf + 64))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->io_px.p, frames + f0 * n, n * 2 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
+        std::vector<std::vector<uint8_t>> blobs; std::vector<int32_t> st;
+        if ((rc = wv_compress_frames(s, nf, rows, cols, applied, blobs, st))) return rc;
+        for (int i = 0; i < nf; i++) {
+            uint8_t *o = out + (f0 + (size_t)i) * out_stride;
+            status[f0 + (size_t)i] = st[(size_t)i]; out_lens[f0 + (size_t)i] = 0;
+            if (st[(size_t)i] != MIC_OK) continue;
+            if (11 + blobs[(size_t)i].size() > out_stride) { status[f0 + (size_t)i] = MIC_ERR_CAPACITY; continue; }
+            wv_put_header(o, rows, cols, max_value, applied);
+            memcpy(o + 11, blobs[(size_t)i].data(), blobs[(size_t)i].size());
+            out_lens[f0 + (size_t)i] = 11 + blobs[(size_t)i].size();
+        }
+    }
+    return MIC_OK;
+}
+
+// WaveletV2RLEFSECompressU16 / WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303, :374)
+int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint16_t max_value, int levels,
+                                uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!pixels || !out || !out_len || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
+    if (out_cap < 11) return MIC_ERR_CAPACITY;
+    size_t len = 0; int32_t st = 0;
+    const int rc = mic_hip_wavelet_v2_compress_batch(pixels, 1, rows, cols, max_value, levels, out, out_cap, &len, &st);
+    if (rc) return rc;
+    if (st != MIC_OK) return st;
+    *out_len = len;
+    return MIC_OK;
 }
 
 int mic_hip_wavelet_v2_info(const uint8_t *c, size_t len, int *rows, int *cols, int *max_value, int *levels) {
@@ -368,50 +459,60 @@ int mic_hip_wavelet_v2_info(const uint8_t *c, size_t len, int *rows, int *cols, 
     return MIC_OK;
 }
 
-// WaveletV2RLEFSEDecompressU16 / WaveletV2SIMDRLEFSEDecompressU16 (:380-425, :493-534)
-int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) {
-    if (!c || !pixels_out) return MIC_ERR_ARGS;
+// WaveletV2RLEFSEDecompressU16 over nframes files of ONE shape (same rows, cols, levels) in one launch chain; pixels_out receives
+// nframes x rows*cols u16, status[i] frame i's status.  Files of another shape than the first: MIC_ERR_ARGS for that frame.
+int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_t *lens, int nframes, uint16_t *pixels_out, size_t out_cap_px,
+                                        int32_t *status) {
+    if (!files || !lens || !pixels_out || !status || nframes <= 0) return MIC_ERR_ARGS;
     int rows, cols, maxv, levels;
-    int rc = mic_hip_wavelet_v2_info(c, len, &rows, &cols, &maxv, &levels);
+    int rc = mic_hip_wavelet_v2_info(files[0], lens[0], &rows, &cols, &maxv, &levels);
     if (rc) return rc;
     if (rows <= 0 || cols <= 0 || levels > 8) return MIC_ERR_CORRUPT;
     const size_t n = (size_t)rows * (size_t)cols;
     if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
-    if (n > out_cap_px) return MIC_ERR_CAPACITY;
-    if (len < 13 || c[11] != 0xFF || c[12] != 0x04) return MIC_ERR_CORRUPT;                 // FSEDecompressU16FourState only, :503
+    if (n * (size_t)nframes > out_cap_px) return MIC_ERR_CAPACITY;
     std::lock_guard<std::mutex> lk(g_mu);
     if ((rc = ensure_device())) return rc;
     mic_hip_session *s = &g_default;
-    if ((rc = s->ensure(1, 2 * n + 16))) return rc;
-    if ((rc = s->io_comp.reserve(len + 64)) || (rc = s->io_px.reserve(n * 2 + 64))) return rc;
-    DevBuf a, b;
-    if ((rc = a.reserve(n * 4 + 64)) || (rc = b.reserve(n * 4 + 64))) { a.release(); b.release(); return rc; }
-    auto done = [&](int code) { a.release(); b.release(); return code; };
-    if (hipMemcpyAsync(s->io_comp.p, c + 11, len - 11, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    s->h_units.assign(1, MicUnit{});
-    MicUnit &u = s->h_units[0];
-    u.comp_in = (const uint8_t *)s->io_comp.p; u.comp_len = (uint32_t)(len - 11); u.w = 1; u.h = 1; u.mode = 1;
-    s->fill_workspace(u, 0);
-    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
-    if (hipMemsetAsync(A, 0, n * 4, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
-    const WvDims d = wv_dims(rows, cols, levels);
-    hipLaunchKernelGGL(k_wv_expand, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
-    hipLaunchKernelGGL(k_wv_coeffs, dim3(1), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
-    for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
-        const int r = d.nr[l], cc = d.nc[l];
-        hipLaunchKernelGGL(k_wv_inv_cols, dim3(grid_for((size_t)r * cc)), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols);
-        hipLaunchKernelGGL(k_wv_inv_rows, dim3(grid_for((size_t)r * cc)), dim3(256), 0, s->stream, (const int32_t *)B, A, r, cc, cols);
+    const size_t per = wv_frames_per_batch(n);
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += per) {
+        const int nf = (int)std::min(per, (size_t)nframes - f0);
+        std::vector<int> slot((size_t)nf, -1); std::vector<uint64_t> offs(1, 0); int good = 0;   // streams packed back to back
+        for (int i = 0; i < nf; i++) {
+            const uint8_t *c = files[f0 + (size_t)i]; const size_t len = lens[f0 + (size_t)i];
+            int r2, c2, m2, l2;
+            status[f0 + (size_t)i] = MIC_OK;
+            if (!c) { status[f0 + (size_t)i] = MIC_ERR_ARGS; continue; }
+            if (mic_hip_wavelet_v2_info(c, len, &r2, &c2, &m2, &l2) != MIC_OK) { status[f0 + (size_t)i] = MIC_ERR_CORRUPT; continue; }
+            if (r2 != rows || c2 != cols || l2 != levels) { status[f0 + (size_t)i] = MIC_ERR_ARGS; continue; }
+            if (len < 13 || c[11] != 0xFF || c[12] != 0x04 || len - 11 > 0xFFFFFFF0ull) { status[f0 + (size_t)i] = MIC_ERR_CORRUPT; continue; }   // FSEDecompressU16FourState only, :503
+            slot[(size_t)i] = good++; offs.push_back(offs.back() + (len - 11));
+        }
+        if (!good) continue;
+        if ((rc = s->ensure(good, 2 * n + 16))) return rc;
+        if ((rc = s->io_comp.reserve((size_t)offs.back() + 64)) || (rc = s->io_px.reserve(n * 2 * (size_t)good + 64))) return rc;
+        for (int i = 0; i < nf; i++) if (slot[(size_t)i] >= 0)
+            HIP_TRY(hipMemcpyAsync((uint8_t *)s->io_comp.p + offs[(size_t)slot[(size_t)i]], files[f0 + (size_t)i] + 11, lens[f0 + (size_t)i] - 11,
+                                   hipMemcpyHostToDevice, s->stream));
+        std::vector<int32_t> st;
+        if ((rc = wv_decompress_frames(s, good, offs, rows, cols, levels, st))) return rc;
+        for (int i = 0; i < nf; i++) if (slot[(size_t)i] >= 0) {
+            const size_t k = (size_t)slot[(size_t)i];
+            status[f0 + (size_t)i] = st[k];
+            if (st[k] == MIC_OK)
+                HIP_TRY(hipMemcpyAsync(pixels_out + (f0 + (size_t)i) * n, (uint16_t *)s->io_px.p + k * n, n * 2, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
     }
-    hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n)), dim3(256), 0, s->stream, (const int32_t *)A, (uint16_t *)s->io_px.p, n);
-    if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
-    s->n_last = 1;
+    return MIC_OK;
+}
+
+// WaveletV2RLEFSEDecompressU16 / WaveletV2SIMDRLEFSEDecompressU16 (:380-425, :493-534)
+int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) {
+    if (!c || !pixels_out) return MIC_ERR_ARGS;
     int32_t st = 0;
-    if ((rc = session_decode_finish(s, &st))) return done(rc);
-    if (st != MIC_OK) return done(st);
-    if (hipMemcpy(pixels_out, s->io_px.p, n * 2, hipMemcpyDeviceToHost) != hipSuccess) return done(MIC_ERR_DEVICE);
-    return done(MIC_OK);
+    const int rc = mic_hip_wavelet_v2_decompress_batch(&c, &len, 1, pixels_out, out_cap_px, &st);
+    return rc ? rc : st;
 }
 
 }  // extern "C"

@@ -671,3 +671,23 @@ def test_session_device_resident_units(mic, mico, synth, gpu_ready):
             sess.encode_enqueue(d_px.data_ptr(), mic.Session.make_units([(0, W, 8, 4095, 2 | 0x400)]))
     finally:
         sess.close()
+
+
+def test_wavelet_batch_matches_single_calls(mic, mico, synth, gpu_ready):
+    """mic_hip_wavelet_v2_{compress,decompress}_batch: every frame's file equals the oracle's single-image file; a frame that
+    fails or a file of another shape is reported per frame."""
+    base = synth.xr_like(cols=301, rows=203, depth=12, seed=3)
+    frames = np.stack([np.roll(base, 5 * k, axis=1) + np.uint16(k) for k in range(7)])
+    res = mic.wavelet_v2_compress_batch(frames, 4095 + 7, levels=4)
+    files = []
+    for k, (st, blob) in enumerate(res):
+        rc, want = mico.wavelet_v2_compress(frames[k], 4095 + 7, 4)
+        assert st == rc and (rc != 0 or blob == want), k
+        files.append(want)
+    sts, back = mic.wavelet_v2_decompress_batch(files)
+    assert sts == [0] * 7 and np.array_equal(back, frames)
+    other = mic.wavelet_v2_compress(base[:100, :150], 100, 150, 4095, 3)
+    broken = bytearray(files[2]); broken[12] = 0x02                           # not a four-state stream (:503)
+    sts, back = mic.wavelet_v2_decompress_batch([files[0], other, bytes(broken), files[3]])
+    assert sts[0] == 0 and sts[3] == 0 and sts[1] == mic.MIC_ERR_ARGS and sts[2] != 0
+    assert np.array_equal(back[0], frames[0]) and np.array_equal(back[3], frames[3])

@@ -22,6 +22,15 @@ blob, te = timed(lambda: mic.wavelet_v2_compress(cr, rows, cols, 4095, 5))
 assert np.array_equal(np.asarray(px).reshape(cr.shape), cr)
 print(f"WaveletV2 CR {cols}x{rows}: ratio {cr.nbytes / len(blob):.3f}  encode {cr.nbytes / te / 1e6:.0f} MB/s  decode {cr.nbytes / td / 1e6:.0f} MB/s")
 
+NB = int(os.environ.get("WV_FRAMES", "48"))
+stack = np.stack([np.roll(cr, 7 * k, axis=1) for k in range(NB)])
+res, te = timed(lambda: mic.wavelet_v2_compress_batch(stack, 4095, 5), reps=2)
+assert all(st == 0 for st, _ in res) and res[0][1] == blob
+files = [b for _, b in res]
+(sts, back), td = timed(lambda: mic.wavelet_v2_decompress_batch(files), reps=2)
+assert sts == [0] * NB and np.array_equal(back, stack)
+print(f"WaveletV2 CR batch of {NB}: encode {stack.nbytes / te / 1e6:.0f} MB/s  decode {stack.nbytes / td / 1e6:.0f} MB/s  (host buffers, wall clock)")
+
 S = int(os.environ.get("SLIDE", "8192"))
 slide = synth.wsi_like(S, S, seed=4)
 blob, te = timed(lambda: mic.compress_wsi(slide, S, S), reps=2)
