@@ -389,6 +389,107 @@ int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *
 }
 
 // ---- PICS (parallelstrips.go) ----------------------------------------------------------------
+// Units cut out of ONE host pixel buffer (the strips of an image, the frames of a stack): the buffer is uploaded once, the units are
+// coded in sub-batches that keep the workspace bounded, and the streams come back into one exactly-sized host vector
+// (no per-unit worst-case staging).  res[i] = {status, offset into store, length}.
+struct UnitResult { int32_t status; size_t off, len; };
+static int encode_units_of_buffer(const uint16_t *pixels, size_t total_px, const std::vector<mic_hip_unit> &units,
+                                  std::vector<UnitResult> &res, std::vector<uint8_t> &store) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if ((rc = s->ensure(1, 1))) return rc;                                  // (the stream)
+    if ((rc = s->io_px.reserve(total_px * 2 + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->io_px.p, pixels, total_px * 2, hipMemcpyHostToDevice, s->stream));
+    const int n = (int)units.size();
+    res.assign((size_t)n, UnitResult{ MIC_OK, 0, 0 });
+    store.clear();
+    int i0 = 0;
+    while (i0 < n) {
+        size_t max_px = 0; int i1 = i0;
+        while (i1 < n) {
+            const size_t px = (size_t)units[(size_t)i1].width * (size_t)units[(size_t)i1].height;
+            if (px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+            const size_t mp = std::max(max_px, px);
+            if (i1 > i0 && unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > kWorkspaceBudget) break;
+            max_px = mp; i1++;
+        }
+        const int nb = i1 - i0;
+        if ((rc = session_encode_enqueue(s, (const uint16_t *)s->io_px.p, units.data() + i0, nb))) return rc;
+        std::vector<uint64_t> offs((size_t)nb + 1); std::vector<int32_t> st((size_t)nb), ns((size_t)nb);
+        const uint8_t *d_blobs = nullptr;
+        if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data()))) return rc;
+        const size_t base = store.size();
+        store.resize(base + (size_t)offs[(size_t)nb]);
+        if (offs[(size_t)nb]) HIP_TRY(hipMemcpy(store.data() + base, d_blobs, (size_t)offs[(size_t)nb], hipMemcpyDeviceToHost));
+        for (int k = 0; k < nb; k++)
+            res[(size_t)(i0 + k)] = UnitResult{ st[(size_t)k], base + (size_t)offs[(size_t)k], (size_t)(offs[(size_t)k + 1] - offs[(size_t)k]) };
+        i0 = i1;
+    }
+    return MIC_OK;
+}
+
+// The mirror image for decode: the streams of the units lie inside ONE host buffer (a container file) and their pixels form one
+// contiguous image / stack.  The file goes up once, the units are decoded in sub-batches, the pixels come down once.
+struct UnitSpan { size_t start, len; uint64_t px_offset; int32_t width, height; uint16_t flags; };
+static int decode_units_of_file(const uint8_t *file, size_t file_len, const std::vector<UnitSpan> &spans, size_t total_px,
+                                uint16_t *pixels_out, std::vector<int32_t> &status) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_device();
+    if (rc) return rc;
+    mic_hip_session *s = &g_default;
+    if ((rc = s->ensure(1, 1))) return rc;
+    if ((rc = s->io_comp.reserve(file_len + 64)) || (rc = s->io_px.reserve(total_px * 2 + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->io_comp.p, file, file_len, hipMemcpyHostToDevice, s->stream));
+    const int n = (int)spans.size();
+    status.assign((size_t)n, MIC_OK);
+    int i0 = 0;
+    while (i0 < n) {
+        size_t max_px = 0; int i1 = i0;
+        while (i1 < n) {
+            const UnitSpan &u = spans[(size_t)i1];
+            if (u.width <= 0 || u.height <= 0 || u.len == 0 || u.len > 0xFFFFFFF0ull || u.start + u.len > file_len) break;   // reported below
+            const size_t px = (size_t)u.width * (size_t)u.height;
+            if (px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+            const size_t mp = std::max(max_px, px);
+            if (i1 > i0 && unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > kWorkspaceBudget) break;
+            max_px = mp; i1++;
+        }
+        if (i1 == i0) {                                                     // a span that cannot be decoded at all
+            const UnitSpan &u = spans[(size_t)i0];
+            status[(size_t)i0] = (u.len == 0 || u.start + u.len > file_len) ? MIC_ERR_CORRUPT : MIC_ERR_ARGS;
+            i0++; continue;
+        }
+        const int nb = i1 - i0;
+        if ((rc = s->ensure(nb, max_px))) return rc;
+        s->h_units.assign((size_t)nb, MicUnit{});
+        bool any_grad = false;
+        for (int k = 0; k < nb; k++) {
+            const UnitSpan &sp = spans[(size_t)(i0 + k)];
+            MicUnit &u = s->h_units[(size_t)k];
+            u.comp_in = (const uint8_t *)s->io_comp.p + sp.start; u.comp_len = (uint32_t)sp.len;
+            u.px_out = (uint16_t *)s->io_px.p + sp.px_offset;
+            u.w = sp.width; u.h = sp.height;
+            u.pred = (sp.flags & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
+            s->fill_workspace(u, k);
+            u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
+        }
+        HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)nb, s->stream));
+        mic_launch_decode((MicUnit *)s->units.p, nb, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), nullptr);
+        HIP_TRY(hipGetLastError());
+        s->n_last = nb;
+        std::vector<int32_t> st((size_t)nb);
+        if ((rc = session_decode_finish(s, st.data()))) return rc;
+        for (int k = 0; k < nb; k++) status[(size_t)(i0 + k)] = st[(size_t)k];
+        i0 = i1;
+    }
+    for (int32_t v : status) if (v != MIC_OK) return MIC_OK;               // the caller reports the first failing unit; no pixels owed
+    HIP_TRY(hipMemcpy(pixels_out, s->io_px.p, total_px * 2, hipMemcpyDeviceToHost));
+    return MIC_OK;
+}
+
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
                           uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
@@ -398,23 +499,18 @@ int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_
     int actual = (height + strip_h - 1) / strip_h;                   // :72
     size_t header = 20 + (size_t)actual * 8;
     if (out_cap < header) return MIC_ERR_CAPACITY;
-    std::vector<mic_hip_enc_job> jobs((size_t)actual);
-    std::vector<std::vector<uint8_t>> bufs((size_t)actual);
+    std::vector<mic_hip_unit> units((size_t)actual);
     for (int s = 0; s < actual; s++) {
-        int y0 = s * strip_h, y1 = std::min(height, y0 + strip_h);
-        mic_hip_enc_job &j = jobs[(size_t)s];
-        j = mic_hip_enc_job{};
-        j.pixels = pixels + (size_t)y0 * (size_t)width; j.width = width; j.height = y1 - y0;
-        j.max_value = max_value; j.nstates = (uint16_t)nstates;       // global maxValue for every strip, :88
-        bufs[(size_t)s].resize(MIC_HIP_FRAME_BOUND((size_t)width * (size_t)(y1 - y0)));
-        j.out = bufs[(size_t)s].data(); j.out_cap = bufs[(size_t)s].size();
+        const int y0 = s * strip_h, y1 = std::min(height, y0 + strip_h);
+        units[(size_t)s] = mic_hip_unit{ (uint64_t)y0 * (uint64_t)width, width, y1 - y0, max_value, (uint16_t)nstates };   // global maxValue for every strip, :88
     }
-    int rc = mic_hip_compress_batch(jobs.data(), actual);
+    std::vector<UnitResult> res; std::vector<uint8_t> store;
+    int rc = encode_units_of_buffer(pixels, (size_t)width * (size_t)height, units, res, store);
     if (rc) return rc;
     size_t total = 0;
     for (int s = 0; s < actual; s++) {
-        if (jobs[(size_t)s].status != MIC_OK) return jobs[(size_t)s].status;   // first failing strip, :95-99
-        total += jobs[(size_t)s].out_len;
+        if (res[(size_t)s].status != MIC_OK) return res[(size_t)s].status;   // first failing strip, :95-99
+        total += res[(size_t)s].len;
     }
     if (total > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;
     if (out_cap < header + total) return MIC_ERR_CAPACITY;
@@ -424,9 +520,9 @@ int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_
     size_t off = 0;
     for (int s = 0; s < actual; s++) {
         put_u32(out + 20 + (size_t)s * 8, (uint32_t)off);
-        put_u32(out + 24 + (size_t)s * 8, (uint32_t)jobs[(size_t)s].out_len);
-        memcpy(out + header + off, jobs[(size_t)s].out, jobs[(size_t)s].out_len);
-        off += jobs[(size_t)s].out_len;
+        put_u32(out + 24 + (size_t)s * 8, (uint32_t)res[(size_t)s].len);
+        memcpy(out + header + off, store.data() + res[(size_t)s].off, res[(size_t)s].len);
+        off += res[(size_t)s].len;
     }
     *out_len = header + total;
     return MIC_OK;
@@ -449,21 +545,19 @@ int mic_hip_pics_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, 
     if (rc) return rc;
     if (w != width || h != height) return MIC_ERR_ARGS;
     size_t header = 20 + (size_t)n * 8;
-    std::vector<mic_hip_dec_job> jobs((size_t)n);
+    std::vector<UnitSpan> spans((size_t)n);
     for (int s = 0; s < n; s++) {
         size_t so = get_u32(c + 20 + (size_t)s * 8), sl = get_u32(c + 24 + (size_t)s * 8);
         size_t start = header + so, end = start + sl;
         if (end > len || start > end) return MIC_ERR_CORRUPT;            // :300-304
         long y0 = (long)s * sh, y1 = std::min<long>(h, y0 + sh);
         if (y0 >= h) return MIC_ERR_CORRUPT;
-        mic_hip_dec_job &j = jobs[(size_t)s];
-        j = mic_hip_dec_job{};
-        j.compressed = c + start; j.compressed_len = sl;
-        j.pixels_out = pixels_out + (size_t)y0 * (size_t)w; j.width = w; j.height = (int)(y1 - y0);
+        spans[(size_t)s] = UnitSpan{ start, sl, (uint64_t)y0 * (uint64_t)w, w, (int32_t)(y1 - y0), 0 };
     }
-    rc = mic_hip_decompress_batch(jobs.data(), n);
+    std::vector<int32_t> st;
+    rc = decode_units_of_file(c, len, spans, (size_t)w * (size_t)h, pixels_out, st);
     if (rc) return rc;
-    for (int s = 0; s < n; s++) if (jobs[(size_t)s].status != MIC_OK) return jobs[(size_t)s].status;
+    for (int s = 0; s < n; s++) if (st[(size_t)s] != MIC_OK) return st[(size_t)s];
     return MIC_OK;
 }
 
@@ -474,19 +568,13 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     size_t npx = (size_t)width * (size_t)height;
     size_t header = 20 + (size_t)nframes * 8;
     if (out_cap < header) return MIC_ERR_CAPACITY;
-    std::vector<mic_hip_enc_job> jobs((size_t)nframes);
-    const size_t fcap = MIC_HIP_FRAME_BOUND(npx);
-    std::vector<uint8_t> buf(fcap * (size_t)nframes);
-    for (int i = 0; i < nframes; i++) {
-        mic_hip_enc_job &j = jobs[(size_t)i];
-        j = mic_hip_enc_job{};
-        j.pixels = frames + npx * (size_t)i; j.width = width; j.height = height; j.max_value = max_value; j.nstates = 2;
-        j.out = buf.data() + fcap * (size_t)i; j.out_cap = fcap;
-    }
-    int rc = mic_hip_compress_batch(jobs.data(), nframes);
+    std::vector<mic_hip_unit> units((size_t)nframes);
+    for (int i = 0; i < nframes; i++) units[(size_t)i] = mic_hip_unit{ (uint64_t)npx * (uint64_t)i, width, height, max_value, 2 };
+    std::vector<UnitResult> res; std::vector<uint8_t> store;
+    int rc = encode_units_of_buffer(frames, npx * (size_t)nframes, units, res, store);
     if (rc) return rc;
     size_t total = 0;
-    for (int i = 0; i < nframes; i++) { if (jobs[(size_t)i].status != MIC_OK) return jobs[(size_t)i].status; total += jobs[(size_t)i].out_len; }
+    for (int i = 0; i < nframes; i++) { if (res[(size_t)i].status != MIC_OK) return res[(size_t)i].status; total += res[(size_t)i].len; }
     if (total > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;              // u32 offsets, multiframe.go:75-80
     if (out_cap < header + total) return MIC_ERR_CAPACITY;
     memset(out, 0, header);
@@ -496,9 +584,9 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     size_t off = 0;
     for (int i = 0; i < nframes; i++) {
         put_u32(out + 20 + (size_t)i * 8, (uint32_t)off);
-        put_u32(out + 24 + (size_t)i * 8, (uint32_t)jobs[(size_t)i].out_len);
-        memcpy(out + header + off, jobs[(size_t)i].out, jobs[(size_t)i].out_len);
-        off += jobs[(size_t)i].out_len;
+        put_u32(out + 24 + (size_t)i * 8, (uint32_t)res[(size_t)i].len);
+        memcpy(out + header + off, store.data() + res[(size_t)i].off, res[(size_t)i].len);
+        off += res[(size_t)i].len;
     }
     *out_len = header + total;
     return MIC_OK;
@@ -529,17 +617,16 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     if (npx * (size_t)n > frames_cap_px) return MIC_ERR_CAPACITY;
     if (temporal) return mic2_temporal_decompress(c, len, w, h, n, n, frames_out);   // mic_temporal.hip
     size_t data_off = 20 + (size_t)n * 8;
-    std::vector<mic_hip_dec_job> jobs((size_t)n);
+    std::vector<UnitSpan> spans((size_t)n);
     for (int i = 0; i < n; i++) {
         size_t start = data_off + get_u32(c + 20 + (size_t)i * 8), bl = get_u32(c + 24 + (size_t)i * 8);
         if (start + bl > len) return MIC_ERR_CORRUPT;                     // multiframe.go:137-139
-        mic_hip_dec_job &j = jobs[(size_t)i];
-        j = mic_hip_dec_job{};
-        j.compressed = c + start; j.compressed_len = bl; j.pixels_out = frames_out + npx * (size_t)i; j.width = w; j.height = h;
+        spans[(size_t)i] = UnitSpan{ start, bl, (uint64_t)npx * (uint64_t)i, w, h, 0 };
     }
-    rc = mic_hip_decompress_batch(jobs.data(), n);
+    std::vector<int32_t> st;
+    rc = decode_units_of_file(c, len, spans, npx * (size_t)n, frames_out, st);
     if (rc) return rc;
-    for (int i = 0; i < n; i++) if (jobs[(size_t)i].status != MIC_OK) return jobs[(size_t)i].status;
+    for (int i = 0; i < n; i++) if (st[(size_t)i] != MIC_OK) return st[(size_t)i];
     return MIC_OK;
 }
 
