@@ -13,8 +13,10 @@ independent, so each GPU codes its own batch (weak scaling, no data-path collect
 value        = raw u16 bytes of the batch (all ranks) / time of one encode+decode step.
 roofline     = dominant kernel: algorithmic bytes (raw + compressed) per launch
                / its mean HIP-event duration on the session stream, against 8 TB/s HBM.
-cpu_baseline = the CPU oracle (port of the Go path) coding the same PICS-8 frames on the
-               host cores, one strip per thread (the mic_parallel.c model).
+cpu_baseline = the reference's own C codec (ojph/mic_compress_c.c + mic_decompress_c.c, built in place into
+               oracle/_ref/libmic_ref.so; kind "reference") coding the strips of the same frames on the host
+               cores, one strip per thread (the mic_parallel.c model); the CPU oracle (kind "port") is timed the
+               same way and reported beside it, and stands in when the reference build is not there.
 """
 import argparse
 import importlib
@@ -41,23 +43,55 @@ def pics_strips(width, height, num_strips):
     return [(i * sh, min(height, (i + 1) * sh)) for i in range(actual)]
 
 
-def cpu_baseline(mico, img, maxv, strips, budget_s=12.0):
-    """PICS-8 encode+decode with the oracle, one strip per thread."""
+def load_reference_codec():
+    """the reference's C codec as built by `make -C oracle ref` (mic_compress_c.h:26-38, mic_decompress_c.h:24-50), or None"""
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle", "_ref", "libmic_ref.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        L = C.CDLL(path)
+        L.mic_compress_two_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mic_decompress_two_state_simd.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        return L
+    except (OSError, AttributeError):
+        return None
+
+
+def cpu_baseline(mico, img, maxv, strips, budget_s=12.0, ref=None):
+    """PICS-8 style encode+decode of one frame's strips, one strip per thread: with the reference C codec when ref is given
+    (two-state encode, its SIMD two-state decode), else with the oracle."""
+    import ctypes as C
     h, w = img.shape
     bounds = pics_strips(w, h, strips)
     cores = max(1, min(len(bounds), os.cpu_count() or 1))
     parts = [np.ascontiguousarray(img[a:b]) for a, b in bounds]
 
-    def enc(p):
-        rc, blob = mico.compress_single_frame(p, maxv, 2)
-        assert rc == 0
-        return blob
+    if ref is not None:
+        def enc(p):
+            out = np.empty(p.size * 4 + 135168, dtype=np.uint8)
+            n = C.c_size_t(0)
+            rc = ref.mic_compress_two_state(p.ctypes.data, p.shape[1], p.shape[0], out.ctypes.data, out.size, C.byref(n))
+            assert rc == 0
+            return out[: n.value]
 
-    def dec(args):
-        blob, p = args
-        rc, px = mico.decompress_single_frame(blob, p.shape[1], p.shape[0])
-        assert rc == 0 and np.array_equal(px, p)
-        return 0
+        def dec(args):
+            blob, p = args
+            px = np.empty_like(p)
+            rc = ref.mic_decompress_two_state_simd(blob.ctypes.data, blob.size, px.ctypes.data, p.shape[1], p.shape[0])
+            assert rc == 0 and np.array_equal(px, p)
+            return 0
+    else:
+        def enc(p):
+            rc, blob = mico.compress_single_frame(p, maxv, 2)
+            assert rc == 0
+            return blob
+
+        def dec(args):
+            blob, p = args
+            rc, px = mico.decompress_single_frame(blob, p.shape[1], p.shape[0])
+            assert rc == 0 and np.array_equal(px, p)
+            return 0
 
     reps, t_enc, t_dec = 0, 0.0, 0.0
     t_start = time.perf_counter()
@@ -67,9 +101,10 @@ def cpu_baseline(mico, img, maxv, strips, budget_s=12.0):
             list(ex.map(dec, zip(blobs, parts))); t2 = time.perf_counter()
             t_enc += t1 - t0; t_dec += t2 - t1; reps += 1
     raw = img.nbytes * reps
-    return {"value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+    who = "reference C codec (ojph/mic_compress_c.c two-state, mic_decompress_two_state_simd)" if ref is not None else "oracle (C port of the Go path)"
+    return {"value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores, "kind": "reference" if ref is not None else "port",
             "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
-            "sample": f"{reps} x PICS-{strips} encode+decode of one {w}x{h} frame, oracle (C port of the Go path), one strip per thread"}
+            "sample": f"{reps} x encode+decode of the {len(parts)} strips of one {w}x{h} frame, {who}, one strip per thread"}
 
 
 def main():
@@ -206,7 +241,13 @@ def main():
     if rank == 0 and not args.no_cpu and world == 1:
         from oracle import mico
         mico.lib()
-        out["cpu_baseline"] = cpu_baseline(mico, base[0], maxv, S)
+        ref = load_reference_codec()
+        port = cpu_baseline(mico, base[0], maxv, S, budget_s=8.0)
+        if ref is not None:
+            out["cpu_baseline"] = cpu_baseline(mico, base[0], maxv, S, budget_s=10.0, ref=ref)
+            out["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "encode_GBps", "decode_GBps", "cores")}
+        else:
+            out["cpu_baseline"] = port
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
