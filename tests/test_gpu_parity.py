@@ -691,3 +691,42 @@ def test_wavelet_batch_matches_single_calls(mic, mico, synth, gpu_ready):
     sts, back = mic.wavelet_v2_decompress_batch([files[0], other, bytes(broken), files[3]])
     assert sts[0] == 0 and sts[3] == 0 and sts[1] == mic.MIC_ERR_ARGS and sts[2] != 0
     assert np.array_equal(back[0], frames[0]) and np.array_equal(back[3], frames[3])
+
+
+# ---- the reference's own C codec, where its in-place build travelled with the repo (oracle/_ref, test infrastructure) -----------
+def _ref_codec():
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libmic_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libmic_ref.so not built (needs /root/reference at build time)")
+    L = C.CDLL(path)
+    for name in ("two", "four", "eight"):
+        getattr(L, f"mic_compress_{name}_state").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        getattr(L, f"mic_decompress_{name}_state").argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    return L
+
+
+def test_bitstreams_equal_the_reference_c_codec(mic, synth, gpu_ready):
+    """Same inputs, same bytes: mic_compress_{two,four,eight}_state (ojph/mic_compress_c.c, maxValue = the frame's own maximum) against
+    the library, full-size XR / CT / MR shaped frames and odd ones; each side decodes the other's stream."""
+    import ctypes as C
+    L = _ref_codec()
+    frames = [synth.xr_like(cols=2577, rows=2048, depth=12, seed=31), synth.xr_like(cols=2577, rows=256, depth=12, seed=32),
+              synth.ct_stack(frames=1, size=512, depth=12, seed=5)[0], synth.xr_like(cols=333, rows=77, depth=10, seed=33),
+              np.fromfile(os.path.join(GOLDEN, "CT_512_512_image.bin"), dtype="<u2").reshape(512, 512)]
+    for k, img in enumerate(frames):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        mx = int(img.max())
+        for name, ns in (("two", 2), ("four", 4), ("eight", 8)):
+            out = np.empty(img.size * 4 + 135168, dtype=np.uint8)
+            n = C.c_size_t(0)
+            rc = getattr(L, f"mic_compress_{name}_state")(img.ctypes.data, w, h, out.ctypes.data, out.size, C.byref(n))
+            assert rc == 0, (k, name)
+            want = out[: n.value].tobytes()
+            got = mic.compress_single_frame(img, w, h, mx, ns)
+            assert got == want, (k, name, len(got), len(want))
+            assert np.array_equal(mic.decompress_single_frame(want, w, h), img), (k, name)
+            back = np.empty_like(img)
+            g = np.frombuffer(got, dtype=np.uint8)
+            assert getattr(L, f"mic_decompress_{name}_state")(g.ctypes.data, g.size, back.ctypes.data, w, h) == 0 and np.array_equal(back, img), (k, name)
