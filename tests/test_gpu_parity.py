@@ -730,3 +730,27 @@ def test_bitstreams_equal_the_reference_c_codec(mic, synth, gpu_ready):
             back = np.empty_like(img)
             g = np.frombuffer(got, dtype=np.uint8)
             assert getattr(L, f"mic_decompress_{name}_state")(g.ctypes.data, g.size, back.ctypes.data, w, h) == 0 and np.array_equal(back, img), (k, name)
+
+
+def test_pics_files_decode_with_the_reference_c_decoder(mic, mico, synth, gpu_ready):
+    """mic_decompress_parallel (ojph/mic_parallel.c:49, the reference's own C reader of PICS files, two- and four-state strips) reads
+    the PICS files the library writes, scalar and SIMD inner decoders, any thread count."""
+    import ctypes as C
+    L = _ref_codec()
+    for fn in ("mic_decompress_parallel", "mic_decompress_parallel_scalar"):
+        getattr(L, fn).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    for img, mx in ((synth.xr_like(cols=2577, rows=2048, depth=12, seed=41), 4095), (synth.xr_like(cols=301, rows=203, depth=12, seed=42), 4095)):
+        h, w = img.shape
+        for strips, ns in ((8, 2), (8, 4), (5, 2), (1, 4), (16, 2)):
+            rc, want = mico.pics_compress(img, mx, strips, ns)
+            if rc != 0:                                                  # strips too short for their alphabet: the reference fails too
+                with pytest.raises(mic.MicError) as e:
+                    mic.compress_parallel_strips(img, w, h, mx, strips, ns)
+                assert e.value.code == rc
+                continue
+            blob = np.frombuffer(mic.compress_parallel_strips(img, w, h, mx, strips, ns), dtype=np.uint8)
+            assert blob.tobytes() == want
+            for fn, threads in (("mic_decompress_parallel", 0), ("mic_decompress_parallel", 3), ("mic_decompress_parallel_scalar", 8)):
+                back = np.zeros_like(img)
+                assert getattr(L, fn)(blob.ctypes.data, blob.size, back.ctypes.data, w, h, threads) == 0, (strips, ns, fn)
+                assert np.array_equal(back, img), (strips, ns, fn)
