@@ -11,6 +11,7 @@ from oracle import mico
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"          # frames of up to 3000 x 1600: many tiles, many chunks, long runs
 
 
 def content(w, h, depth):
@@ -47,8 +48,12 @@ def fail(what, img, mv, extra):
 
 t0 = time.time(); n = 0; stats = {}
 while time.time() - t0 < budget:
-    w = int(rng.choice([1, 2, 3, 7, 16, 63, 64, 65, 127, 200, 257, int(rng.integers(1, 400))]))
-    h = int(rng.choice([1, 2, 5, 17, 64, 65, 130, int(rng.integers(1, 300))]))
+    if LARGE:
+        w = int(rng.choice([511, 512, 1000, 2048, 2577, int(rng.integers(300, 3000))]))
+        h = int(rng.choice([64, 255, 256, 257, 700, int(rng.integers(60, 1600))]))
+    else:
+        w = int(rng.choice([1, 2, 3, 7, 16, 63, 64, 65, 127, 200, 257, int(rng.integers(1, 400))]))
+        h = int(rng.choice([1, 2, 5, 17, 64, 65, 130, int(rng.integers(1, 300))]))
     depth = int(rng.integers(4, 17))
     img, mv, kind = content(w, h, depth)
     mode = int(rng.integers(0, 9)); ns = int(rng.choice([2, 4, 8]))
@@ -141,5 +146,5 @@ while time.time() - t0 < budget:
         raise
     stats[(key, rc == 0)] = stats.get((key, rc == 0), 0) + 1
     n += 1
-    if n % 200 == 0: print(f"{n} cases, {time.time() - t0:.0f} s", flush=True)
+    if n % (10 if LARGE else 200) == 0: print(f"{n} cases, {time.time() - t0:.0f} s", flush=True)
 print("OK", n, "cases", sorted(stats.items()))
