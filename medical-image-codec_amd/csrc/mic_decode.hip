@@ -695,10 +695,11 @@ __global__ void __launch_bounds__(64 * T2_WAVES) k_dec_tans_duo(MicUnit *units, 
 #pragma unroll
             for (int k = 0; k < N; k++) sv_st[k] = st[k];
         }
-        for (uint32_t gi = 0; gi < G; gi += 8) {
+        constexpr uint32_t UG = G;                                             // groups per loop body (a taken scalar branch costs tens of cycles)
+        for (uint32_t gi = 0; gi < G; gi += UG) {
             const l16 sg = (l16)(uintptr_t)(stageb + gi * 2);
 #pragma unroll
-            for (int j = 0; j < 8; j++) group(sg + j);
+            for (uint32_t j = 0; j < UG; j++) group(sg + j);
         }
         store_blk(blk - 2, pf0, pf1);
         flush_pend();
