@@ -137,5 +137,15 @@ size_t unit_ws_bytes(size_t px);
 int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
                            uint8_t *out, size_t out_cap, size_t *out_len);
 int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_total, int n, uint16_t *frames_out);
-constexpr size_t kWorkspaceBudget = (size_t)24 << 30;
+// Per-call workspace ceiling: the container entry points cut their unit lists into sub-batches that stay under it.
+// MIC_HIP_WS_BUDGET_MB (read once) lowers it so that tests can walk the sub-batch loops with small inputs.
+inline size_t workspace_budget() {
+    static const size_t v = [] {
+        const char *e = getenv("MIC_HIP_WS_BUDGET_MB");
+        const long mb = e ? atol(e) : 0;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)24 << 30;
+    }();
+    return v;
+}
+#define kWorkspaceBudget (micapi::workspace_budget())
 }  // namespace micapi

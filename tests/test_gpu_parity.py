@@ -754,3 +754,13 @@ def test_pics_files_decode_with_the_reference_c_decoder(mic, mico, synth, gpu_re
                 back = np.zeros_like(img)
                 assert getattr(L, fn)(blob.ctypes.data, blob.size, back.ctypes.data, w, h, threads) == 0, (strips, ns, fn)
                 assert np.array_equal(back, img), (strips, ns, fn)
+
+
+def test_sub_batch_loops(gpu_ready):
+    """The container calls cut long unit lists into sub-batches under a workspace ceiling (24 GiB); with MIC_HIP_WS_BUDGET_MB=8 the same
+    loops run on small inputs (tests/chunking_check.py, a child process: the ceiling is read once per process)."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MIC_HIP_WS_BUDGET_MB="8")
+    r = subprocess.run([sys.executable, os.path.join(here, "chunking_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sub-batch loops ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
