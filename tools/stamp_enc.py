@@ -7,13 +7,14 @@ import torch
 mic = entry.load_package(); synth = importlib.import_module("medical_image_codec_amd.synth")
 W, H = 2577, 2048
 img = synth.xr_like(cols=W, rows=H, depth=12, seed=1)
-d_px = torch.from_numpy(img.view(np.int16)).cuda()
-units = [(y0 * W, W, 256, 4095, int(os.environ.get("NS", "2"))) for y0 in range(0, H, 256)]
+F = int(os.environ.get("FRAMES", "1"))                       # FRAMES=256: the phases under the contention of a full batch
+d_px = torch.from_numpy(np.stack([img] * F).view(np.int16)).cuda()
+units = [(f * W * H + y0 * W, W, 256, 4095, int(os.environ.get("NS", "2"))) for f in range(F) for y0 in range(0, H, 256)]
 sess = mic.Session(len(units), W * 256); cu = mic.Session.make_units(units)
 sess.encode_enqueue(d_px.data_ptr(), cu); d_blobs, offs, st, ns = sess.encode_finish(); assert (st == 0).all()
 buf = (C.c_uint32 * 32)()
 names = ["tok.A symbols", "tok.B facts", "tok.C counts", "tok.D write", "tok.E carry", "tab.normalise", "tab.ncount", "tab.ctable",
          "tans.walk", "tans.fixup", "tans.bits", "tans.pack", "fix.rounds", "fix.rewalkers", "fix.maxgroups", "tok.slow_wavetiles"]
-for i in range(len(units)):
+for i in (range(len(units)) if F == 1 else (0, 1, len(units) // 2, len(units) - 1)):
     mic.lib().mic_hip_debug_unit(sess._h, i, buf)
     print(f"unit {i}: ntok={buf[0]} " + " ".join(f"{n}={buf[16 + k]}" for k, n in enumerate(names)))
