@@ -444,6 +444,12 @@ static int decode_units_of_file(const uint8_t *file, size_t file_len, const std:
     HIP_TRY(hipMemcpyAsync(s->io_comp.p, file, file_len, hipMemcpyHostToDevice, s->stream));
     const int n = (int)spans.size();
     status.assign((size_t)n, MIC_OK);
+    {   // pixels no unit writes come back as zeros, like the reference's make([]uint16, w*h) (parallelstrips.go:288): a PICS header
+        // whose strips do not cover the image is accepted there, and the staging buffer holds an earlier call's pixels
+        size_t covered = 0;
+        for (const UnitSpan &u : spans) if (u.width > 0 && u.height > 0) covered += (size_t)u.width * (size_t)u.height;
+        if (covered < total_px) HIP_TRY(hipMemsetAsync(s->io_px.p, 0, total_px * 2, s->stream));
+    }
     int i0 = 0;
     while (i0 < n) {
         size_t max_px = 0; int i1 = i0;

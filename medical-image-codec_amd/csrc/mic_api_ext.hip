@@ -178,6 +178,14 @@ int parse_mic3(const uint8_t *c, size_t len, Mic3 &m) {                       //
     }
     m.data_off = 48 + 20 * (size_t)m.nlev + 16 * (size_t)m.total;
     if (m.tw <= 0 || m.th <= 0 || (size_t)m.tw * m.th > ((size_t)1 << 26)) return MIC_ERR_CORRUPT;
+    // the level table must be what computeLevels writes (wsiformat.go:244-271): positive dimensions, tile counts that are the
+    // ceilings of dimension / tile size, tile ranges inside the tile table.  The decoders walk tx * ty tiles of a level, so a
+    // descriptor that lies about them would drive the host loops (and int arithmetic) wherever the file says.
+    for (const Level &l : m.lv) {
+        if (l.w <= 0 || l.h <= 0 || l.first < 0) return MIC_ERR_CORRUPT;
+        if ((int64_t)l.tx != ((int64_t)l.w + m.tw - 1) / m.tw || (int64_t)l.ty != ((int64_t)l.h + m.th - 1) / m.th) return MIC_ERR_CORRUPT;
+        if ((uint64_t)l.first + (uint64_t)l.tx * (uint64_t)l.ty > m.total) return MIC_ERR_CORRUPT;
+    }
     return MIC_OK;
 }
 
@@ -193,9 +201,11 @@ int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::v
     const size_t P = (size_t)m.planes(), bpp = m.bpp();
     // per-tile chunking keeps the unit workspace bounded
     const size_t per = std::max<size_t>(1, kWorkspaceBudget / (P * unit_ws_bytes(npx)));
-    DevBuf planes, d_place, d_out;
+    struct Bufs { DevBuf planes, d_place, d_out; ~Bufs() { planes.release(); d_place.release(); d_out.release(); } } bufs;   // freed on every return path
+    DevBuf &planes = bufs.planes, &d_place = bufs.d_place, &d_out = bufs.d_out;
     int rc;
     if ((rc = d_out.reserve((size_t)dst_w * dst_h * bpp + 64))) return rc;
+    if (tiles.empty()) HIP_TRY(hipMemsetAsync(d_out.p, 0, (size_t)dst_w * dst_h * bpp, s->stream));   // nothing will write it
     for (size_t t0 = 0; t0 < ntile && rc == MIC_OK; t0 += per) {
         const size_t nt = std::min(per, ntile - t0);
         if ((rc = planes.reserve(nt * P * npx * 2 + 64))) break;
@@ -259,7 +269,6 @@ int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::v
         hipError_t e = hipMemcpy(rgb_out, d_out.p, (size_t)dst_w * dst_h * bpp, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = MIC_ERR_DEVICE;
     }
-    planes.release(); d_place.release(); d_out.release();
     return rc;
 }
 

@@ -1,0 +1,397 @@
+// mic_decode_ls.hip -- tANS decode with one LANE per (stream, state): nine streams per CU.
+//
+// The N states of an N-state stream (fse2state.go:203-308, fse4state.go:195-353, fse8state.go:230-380,
+// rans8state.go:221-412) share one reverse bitstream, so a stream is a serial chain
+//   state_k -> table entry -> (nbBits, nextState) -> bits at the running position -> state_k'
+// and decode throughput = resident streams / latency of one round of N symbols.  Two things bound it on a
+// CU: the LDS holds the 16-bit nextState tables of at most NINE streams (tableLog 13: 16 KiB each), and a wave issues one
+// instruction per ~4 cycles whatever its lanes do.  The earlier kernel (k_dec_tans_duo, mic_decode.hip) ran every lane of a
+// wave through the same values -- two distinct streams per 64 lanes, N table look-ups issued one after the other -- so it
+// was bound by instructions issued per symbol and got slower with more states.  Here lane g*N + k of a wave owns state k of
+// the wave's stream g (three streams per wave, three waves per group, one group per CU):
+//   * a round = ONE table look-up instruction for all N states of all three streams, nbBits from v_ffbh, the offset of a
+//     state's bits inside the round from a DPP prefix sum over the N lanes of its stream (quad_perm / row_shr: no LDS, no
+//     readlane), the bits from a funnel shift of the stream's bit window, kept in a 256-dword LDS ring;
+//   * N = 2: the 32-bit window is read at the round's start position together with the table look-ups, so a round costs one
+//     LDS round trip (~15 instructions for TWO symbols of THREE streams); N = 4 / 8: every lane reads its own window at its
+//     own bit position once the prefix sum is known: two LDS round trips for 4 / 8 symbols, so more states decode FASTER;
+//   * the lanes of a wave that own no state clone stream 0 (same addresses: LDS broadcasts), all 64 lanes share the
+//     per-chunk work: ring refill (64 dwords per stream and 128 symbols, prefetched a chunk ahead), translation of the 128
+//     staged states to symbols through the L2-resident symbol table, one coalesced 256-byte store per stream, and the RLE
+//     header walk on the tokens still in registers (rledecompressu16.go:59-85), one chunk behind the chain.
+// Streams come from a compacted per-class list (k_dec_classify), so a launch only touches the units of its class.
+// LDS per stream: ring 1024 B | mirror dword + pad 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
+#include "mic_dev.h"
+#include "mic_launch.h"
+
+#define LS_SPW 3                                   // streams per wave
+#define LS_WAVES 3                                 // waves per group (one group per CU: the LDS is full)
+#define LS_TL 13                                   // largest tableLog served here
+#define LS_RING 0u
+#define LS_STAGE 1040u
+#define LS_TAB 1296u
+#define LS_STREAM_BYTES (LS_TAB + (2u << LS_TL))   // 17680
+#define LS_LDS (LS_WAVES * LS_SPW * LS_STREAM_BYTES)   // 159120 of 163840
+#define LS_CLASSES 6                               // (N in 2,4,8) x (zeroBits)
+static_assert(LS_LDS <= 160 * 1024, "one group must fit a CU's LDS");
+
+typedef __attribute__((address_space(3))) uint32_t *ls_l32;
+typedef __attribute__((address_space(3))) uint16_t *ls_l16;
+typedef const __attribute__((address_space(1))) uint16_t *ls_gcu16;
+typedef const __attribute__((address_space(1))) uint32_t *ls_gcu32;
+typedef __attribute__((address_space(1))) uint16_t *ls_gu16;
+typedef __attribute__((address_space(1))) uint32_t *ls_gu32;
+typedef uint32_t ls_v2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL> __device__ __forceinline__ uint32_t ls_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+#define LS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define LS_ROW_SHR(n) (0x110 + (n))
+#define LS_ROW_HALF_MIRROR 0x141
+
+__device__ __forceinline__ uint32_t ls_rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint64_t ls_rl64(uint64_t v, int lane) {
+    return ((uint64_t)ls_rl((uint32_t)(v >> 32), lane) << 32) | ls_rl((uint32_t)v, lane);
+}
+
+// Per-class lists of unit indices, in unit order: list[c * n + i], count[c].  Class = 2 * log2(N / 2) + zeroBits for the
+// N-state streams (rANS-8 decodes as 8-state) with tableLog <= 13; everything else is left to the kernels of mic_decode.hip.
+// One group; the stream checks that need the blob (empty bitstream, zero end byte: bitreader.go:33-38) are made here.
+__global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, int *list, int *count) {
+    __shared__ uint32_t s_w[16][LS_CLASSES];
+    __shared__ uint32_t s_base[LS_CLASSES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < LS_CLASSES) s_base[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)tid;
+        int cls = -1;
+        if (i < n) {
+            MicUnit &u = units[i];
+            const uint32_t flav = u.flavour, tl = u.table_log;
+            const uint32_t ns = (flav == 108) ? 8u : flav;
+            if (u.status == MICD_OK && u.ntok == 0 && (ns == 2 || ns == 4 || ns == 8) && tl >= MIC_MIN_TABLELOG && tl <= LS_TL) {
+                if (u.bits_off >= u.comp_len) u.status = MICD_ERR_CORRUPT;
+                else if (u.comp_len - u.bits_off < (1u << 27)) {            // 32-bit bit positions here; the serial kernel takes longer ones
+                    if (u.comp_in[u.comp_len - 1] == 0) u.status = MICD_ERR_CORRUPT;
+                    else cls = (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
+                }
+            }
+        }
+        uint32_t rank = 0;
+#pragma unroll
+        for (int c = 0; c < LS_CLASSES; c++) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_w[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            uint32_t off = s_base[cls];
+            for (uint32_t w = 0; w < wave; w++) off += s_w[w][cls];
+            list[(size_t)cls * (size_t)n + off + rank] = i;
+        }
+        __syncthreads();
+        if (tid < LS_CLASSES) { uint32_t t = 0; for (int w = 0; w < 16; w++) t += s_w[w][tid]; s_base[tid] += t; }
+        __syncthreads();
+    }
+    if (tid < LS_CLASSES) count[tid] = (int)s_base[tid];
+}
+
+template <int N, bool ZB>
+__global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, const int *list, const int *count_p) {
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout assumes dynamic LDS at 0
+    const int n_cls = *count_p;
+    const int slot0 = ((int)blockIdx.x * LS_WAVES + (int)wv) * LS_SPW;
+    if (slot0 >= n_cls) return;                                             // waves share nothing and never meet at a barrier
+    // ---- roles ----------------------------------------------------------------------------------------------------
+    const uint32_t k = lane % N;                                            // state of the chain this lane runs
+    uint32_t g = lane / N; if (g >= LS_SPW) g = 0;                          // its stream; surplus lanes clone stream 0
+    const bool have = slot0 + (int)g < n_cls;                               // the last wave of a class may hold fewer streams
+    const uint32_t gs = have ? g : 0;                                       // absent streams run on stream 0's table (every access in range)
+    const MicUnit &u = units[list[slot0 + (int)gs]];
+    const uint32_t tl = u.table_log, size = 1u << tl;
+    const uint32_t count = have ? u.count : 0u;
+    const uint32_t bits_off = u.bits_off, len = u.comp_len - bits_off;
+    const uint32_t sbase = (wv * LS_SPW + g) * LS_STREAM_BYTES;             // own ring / stage (also for an absent stream)
+    const uint32_t tbase = (wv * LS_SPW + gs) * LS_STREAM_BYTES + LS_TAB;
+    // ---- tables: u16 nextState = (newState + size) >> nbBits (fsedecompressu16.go:233-241), all 64 lanes per stream ----
+#pragma unroll 1
+    for (int j = 0; j < LS_SPW; j++) {
+        if (slot0 + j >= n_cls) break;
+        const int src = j * N;                                              // a lane that holds stream j's values
+        const uint32_t sz = ls_rl(size, src);
+        const uint32_t *dt = (const uint32_t *)(uintptr_t)ls_rl64((uint64_t)(uintptr_t)u.tt_nb, src);
+        const uint32_t tb = (wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_TAB;
+        for (uint32_t p = lane * 4; p < sz; p += 256) {
+            const uint4 e = *(const uint4 *)(dt + p);
+            const uint32_t n0 = ((e.x & 0xFFFF) + sz) >> (e.x >> 16), n1 = ((e.y & 0xFFFF) + sz) >> (e.y >> 16);
+            const uint32_t n2 = ((e.z & 0xFFFF) + sz) >> (e.z >> 16), n3 = ((e.w & 0xFFFF) + sz) >> (e.w >> 16);
+            ls_v2 v; v.x = n0 | (n1 << 16); v.y = n2 | (n3 << 16);
+            *(__attribute__((address_space(3))) ls_v2 *)(uintptr_t)(tb + p * 2) = v;
+        }
+    }
+    // ---- bit reader (bitreader.go): grid of aligned dwords under the stream; unread bits = grid bits [8*sb, cur) ----
+    const uint8_t *bs = u.comp_in + bits_off;
+    const uint32_t last = bs[len - 1];                                      // non-zero: k_dec_classify
+    const uintptr_t addr = (uintptr_t)bs;
+    const uint32_t sb = (uint32_t)(addr & 3);
+    const uint64_t gaddr = (uint64_t)(addr - sb);
+    const int32_t cur0 = (int32_t)(8u * (len - 1) + (uint32_t)(31 - __clz(last)) + 8u * sb);
+    const int32_t top_dw = have ? (cur0 - 1) >> 5 : -1;
+    int32_t q = cur0 - 32;                                                  // window of a round = grid bits [q, q+32): its MSB is the next unread bit
+    // wave-uniform per-stream values for the shared work
+    bool s_have[LS_SPW]; uint64_t s_g[LS_SPW], s_out[LS_SPW], s_sym[LS_SPW]; int32_t s_top[LS_SPW], s_blk[LS_SPW]; uint32_t s_chunks[LS_SPW];
+#pragma unroll
+    for (int j = 0; j < LS_SPW; j++) {
+        const int src = j * N;
+        s_have[j] = slot0 + j < n_cls;
+        s_g[j] = ls_rl64(gaddr, src);
+        s_out[j] = ls_rl64((uint64_t)(uintptr_t)u.tok, src);
+        s_sym[j] = ls_rl64((uint64_t)(uintptr_t)(u.tab_sym - size), src);  // indexed by the state with its +size offset
+        s_top[j] = (int32_t)ls_rl((uint32_t)top_dw, src);
+        s_chunks[j] = ls_rl(count, src) / 128u;
+        s_blk[j] = ((int32_t)ls_rl((uint32_t)q, src) >> 5) >> 6;
+    }
+    auto load_blk = [&](int j, int32_t b) -> uint32_t {                    // dword `lane` of block b of stream j, zero outside the stream
+        const int32_t idx = b * 64 + (int32_t)lane;
+        return (b >= 0 && idx <= s_top[j]) ? __builtin_nontemporal_load((ls_gcu32)(uintptr_t)s_g[j] + idx) : 0u;   // streamed once
+    };
+    auto store_blk = [&](int j, int32_t b, uint32_t v) {
+        const uint32_t rb = (wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_RING;
+        const uint32_t slot = ((uint32_t)b & 3u) * 64u + lane;
+        *(ls_l32)(uintptr_t)(rb + slot * 4) = v;
+        if (slot == 0) *(ls_l32)(uintptr_t)(rb + 1024) = v;                 // mirror: a 2-dword read at slot 255 stays linear
+    };
+    uint32_t pf[LS_SPW];
+#pragma unroll
+    for (int j = 0; j < LS_SPW; j++) {
+        store_blk(j, s_blk[j] + 1, load_blk(j, s_blk[j] + 1));
+        store_blk(j, s_blk[j], load_blk(j, s_blk[j]));
+        store_blk(j, s_blk[j] - 1, load_blk(j, s_blk[j] - 1));
+        pf[j] = load_blk(j, s_blk[j] - 2);                                  // enters the ring at the end of the first chunk
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                     // wave-private LDS: the writes above are in before the reads below
+    // ---- chain state ---------------------------------------------------------------------------------------------
+    const uint32_t ringb = sbase + LS_RING;
+    const uint32_t stgb = sbase + LS_STAGE + 2u * k;                        // stage16[r * N + k] = state k of round r
+    const uint32_t cb = tbase - 2u * size;                                  // byte address of entry s = 2 * s + cb, s in [size, 2 * size)
+    const uint32_t C = 31u - tl;
+    auto window = [&](int32_t qq) -> uint32_t {
+        const uint32_t a = (__builtin_amdgcn_ubfe((uint32_t)qq, 5, 8) << 2) + ringb;
+        const uint32_t w0 = *(ls_l32)(uintptr_t)a, w1 = *(ls_l32)(uintptr_t)(a + 4);
+        return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)qq);
+    };
+    auto entry = [&](uint32_t s) -> uint32_t { return *(ls_l16)(uintptr_t)(s * 2 + cb); };
+    // initial states: state 0 first, tableLog bits each (fse2state.go:210-212); kept with the +size offset
+    uint32_t st = size + (window(q - (int32_t)(k * tl)) >> (32u - tl));
+    q -= (int32_t)(N * tl);
+    const uint32_t mk1 = (k >= 1) ? ~0u : 0u, mk2 = (k >= 2) ? ~0u : 0u, mk4 = (k >= 4) ? ~0u : 0u;
+    // bits of a round: nb = this state's nbBits, pre = bits the earlier states of the round take, tot = the round's bits
+    auto prefix = [&](uint32_t nb, uint32_t &pre, uint32_t &tot) {
+        if (N == 2) {
+            pre = ls_dpp<LS_QP(0, 0, 2, 2)>(nb) & mk1;
+            tot = nb + ls_dpp<LS_QP(1, 0, 3, 2)>(nb);
+        } else {
+            uint32_t t = nb + (ls_dpp<LS_QP(0, 0, 1, 2)>(nb) & mk1);
+            t = t + (ls_dpp<LS_QP(0, 0, 0, 1)>(t) & mk2);                    // inclusive prefix inside the quad
+            const uint32_t tq = ls_dpp<LS_QP(3, 3, 3, 3)>(t);               // the quad's sum
+            if (N == 4) { pre = t - nb; tot = tq; }
+            else {
+                t = t + (ls_dpp<LS_ROW_SHR(4)>(tq) & mk4);
+                pre = t - nb;
+                tot = tq + ls_dpp<LS_ROW_HALF_MIRROR>(tq);
+            }
+        }
+    };
+    // one round = N symbols of every stream of the wave; stage slot at byte offset soff from stgb
+    auto round = [&](uint32_t soff) {
+        const uint32_t e = entry(st);
+        if (N == 2) {
+            const uint32_t hi = window(q);
+            *(ls_l16)(uintptr_t)(stgb + soff) = (uint16_t)st;
+            const uint32_t c = (uint32_t)__builtin_clz(e);
+            const uint32_t nb = c - C, m = C - c;                           // m = -nbBits: a funnel shift right by m mod 32 = 32 - nbBits
+            uint32_t pre, tot; prefix(nb, pre, tot);
+            const uint32_t hi1 = hi << pre;
+            if (ZB) st = (uint32_t)((((uint64_t)e << 32) | hi1) >> (32u - nb));   // nbBits may be 0: a 64-bit shift by 32 is well defined
+            else st = __builtin_amdgcn_alignbit(e, hi1, m);
+            q -= (int32_t)tot;
+        } else {
+            *(ls_l16)(uintptr_t)(stgb + soff) = (uint16_t)st;
+            const uint32_t c = (uint32_t)__builtin_clz(e);
+            const uint32_t nb = c - C, m = C - c;
+            uint32_t pre, tot; prefix(nb, pre, tot);
+            const uint32_t hi = window(q - (int32_t)pre);                   // this state's own window
+            if (ZB) st = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
+            else st = __builtin_amdgcn_alignbit(e, hi, m);
+            q -= (int32_t)tot;
+        }
+    };
+    // ---- RLE header walkers, one per stream (uniform values; as k_dec_tans_lds, mic_decode.hip) --------------------
+    bool w_on[LS_SPW], w_err[LS_SPW]; uint32_t w_pos[LS_SPW], w_out[LS_SPW], w_nseg[LS_SPW], w_mid[LS_SPW], w_symcap[LS_SPW], w_segcap[LS_SPW], w_cnt[LS_SPW];
+    __attribute__((address_space(1))) ls_v2 *w_seg[LS_SPW];
+#pragma unroll
+    for (int j = 0; j < LS_SPW; j++) {
+        const int src = j * N;
+        const uint32_t on = (have && u.mode == 0 && u.seg != nullptr) ? 1u : 0u;
+        w_on[j] = s_have[j] && ls_rl(on, src) != 0; w_err[j] = false;
+        w_pos[j] = 0; w_out[j] = 0; w_nseg[j] = 0; w_mid[j] = 0;
+        const uint32_t sc = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);
+        w_symcap[j] = ls_rl(sc, src); w_segcap[j] = ls_rl(u.seg_cap, src); w_cnt[j] = ls_rl(count, src);
+        w_seg[j] = (__attribute__((address_space(1))) ls_v2 *)(uintptr_t)ls_rl64((uint64_t)(uintptr_t)u.seg, src);
+    }
+    auto walk = [&](int j, uint32_t cend, auto get) {                       // headers in front of token cend
+        while (w_on[j] && w_pos[j] < cend) {
+            const uint32_t hd = get(w_pos[j]);
+            if (w_pos[j] == 0) {                                            // token 0 fixes the run / literal split
+                const int d0 = mic_len16((uint16_t)hd);
+                if (d0 == 0) { w_on[j] = false; w_err[j] = true; break; }
+                w_mid[j] = (1u << (d0 - 1)) - 1; w_pos[j] = 1;
+                continue;
+            }
+            if (w_out[j] >= w_symcap[j]) { w_on[j] = false; break; }
+            if (hd == 0 || w_nseg[j] >= w_segcap[j]) { w_on[j] = false; w_err[j] = true; break; }
+            if (hd <= w_mid[j]) {
+                if (w_pos[j] + 1 >= w_cnt[j]) { w_on[j] = false; w_err[j] = true; break; }
+                if (lane == 0) { ls_v2 r; r.x = (w_pos[j] + 1) | 0x80000000u; r.y = w_out[j]; w_seg[j][w_nseg[j]] = r; }
+                w_nseg[j]++; w_out[j] += hd; w_pos[j] += 2;
+            } else {
+                if (lane == 0) { ls_v2 r; r.x = w_pos[j] + 1; r.y = w_out[j]; w_seg[j][w_nseg[j]] = r; }
+                w_nseg[j]++; w_out[j] += hd - w_mid[j]; w_pos[j] += 1 + (hd - w_mid[j]);
+            }
+        }
+    };
+    // ---- chunks of 128 symbols per stream ---------------------------------------------------------------------------
+    constexpr uint32_t R = 128 / N;                                         // rounds per chunk
+    const uint32_t chunks = count / 128u, rem = count - chunks * 128u;
+    uint32_t maxch = 0;
+#pragma unroll
+    for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxch = max(maxch, s_chunks[j]);
+    uint32_t pend[LS_SPW] = { 0u, 0u, 0u }; bool have_pend = false; uint32_t pch = 0;   // lane l: tokens 2l, 2l+1 of the previous chunk
+    auto flush_pend = [&]() {
+        if (!have_pend) return;
+        const uint32_t cbase = pch * 128u;
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) {
+            if (s_have[j] && pch < s_chunks[j]) {
+                const uint32_t pk = pend[j];
+                __builtin_nontemporal_store(pk, (ls_gu32)(uintptr_t)s_out[j] + pch * 64u + lane);
+                walk(j, cbase + 128u, [&](uint32_t pos) -> uint32_t {
+                    const uint32_t rel = pos - cbase;
+                    const uint32_t d = ls_rl(pk, (int)(rel >> 1));
+                    return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
+                });
+            }
+        }
+    };
+    uint32_t sv_st = st; int32_t sv_q = q;                                  // a shorter stream's true state after its last whole chunk
+    for (uint32_t ch = 0; ch < maxch; ch++) {
+        if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
+        // the chunk's states are staged: ring upkeep, write out the previous chunk, gather this one
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) if (s_have[j]) store_blk(j, s_blk[j] - 2, pf[j]);
+        flush_pend();
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) {
+            if (!s_have[j]) continue;
+            s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
+            pf[j] = load_blk(j, s_blk[j] - 2);
+            const uint32_t s2 = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
+            const ls_gcu16 sy = (ls_gcu16)(uintptr_t)s_sym[j];
+            pend[j] = (ch < s_chunks[j]) ? ((uint32_t)sy[s2 & 0xFFFFu] | ((uint32_t)sy[s2 >> 16] << 16)) : 0u;   // (a finished stream decodes garbage: keep it off the table)
+        }
+        have_pend = true; pch = ch;
+    }
+    flush_pend();
+    if (chunks < maxch) { st = sv_st; q = sv_q; }                           // (per lane) back to the true end-of-chunks state
+    if (maxch) {   // ... and the rings back to where those states read (the run-off moved them on); harmless for the longest stream
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) {
+            if (!s_have[j]) continue;
+            const int32_t b = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
+            store_blk(j, b + 1, load_blk(j, b + 1)); store_blk(j, b, load_blk(j, b)); store_blk(j, b - 1, load_blk(j, b - 1));
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    // ---- tails: rem < 128 tokens per stream; a state past the stream's last token neither moves nor takes bits ----------
+    {
+        uint32_t maxrem = 0;
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxrem = max(maxrem, ls_rl(rem, j * N));
+#pragma unroll 1
+        for (uint32_t r = 0; r * N < maxrem; r++) {
+            const bool valid = r * N + k < rem;                             // fse2state.go:293-305 and siblings: the last states in lane order
+            const uint32_t e = entry(st);
+            *(ls_l16)(uintptr_t)(stgb + r * N * 2u) = (uint16_t)st;
+            const uint32_t nbr = (uint32_t)__builtin_clz(e) - C;
+            const uint32_t nb = valid ? nbr : 0u;
+            uint32_t pre, tot; prefix(nb, pre, tot);
+            const uint32_t hi = window(q - (int32_t)pre);
+            const uint32_t nx = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
+            st = valid ? nx : st;
+            q -= (int32_t)tot;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int j = 0; j < LS_SPW; j++) {
+            if (!s_have[j]) continue;
+            const uint32_t rj = ls_rl(rem, j * N), done = s_chunks[j] * 128u;
+            const uint32_t s2 = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
+            const ls_gcu16 sy = (ls_gcu16)(uintptr_t)s_sym[j];
+            const ls_gu16 o = (ls_gu16)(uintptr_t)s_out[j];
+            uint32_t t0 = 0, t1 = 0;
+            if (2 * lane < rj) { t0 = sy[s2 & 0xFFFFu]; o[done + 2 * lane] = (uint16_t)t0; }
+            if (2 * lane + 1 < rj) { t1 = sy[s2 >> 16]; o[done + 2 * lane + 1] = (uint16_t)t1; }
+            const uint32_t pk = t0 | (t1 << 16);
+            walk(j, w_cnt[j], [&](uint32_t pos) -> uint32_t {
+                const uint32_t rel = pos - done;
+                const uint32_t d = ls_rl(pk, (int)(rel >> 1));
+                return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
+            });
+        }
+    }
+    // ---- results: one lane per stream -------------------------------------------------------------------------------
+    if (have && k == 0 && lane < LS_SPW * N) {
+        MicUnit &uo = units[list[slot0 + (int)g]];
+        if (q + 32 - (int32_t)(8u * sb) < 0) uo.status = MICD_ERR_CORRUPT;  // bitreader.go:113-120: more bits taken than the stream holds
+        else {
+            uo.ntok = count;
+            const bool werr = g == 0 ? w_err[0] : g == 1 ? w_err[1] : w_err[2];
+            if (uo.mode == 0 && uo.seg != nullptr && !werr) {
+                uo.nseg = g == 0 ? w_nseg[0] : g == 1 ? w_nseg[1] : w_nseg[2];
+                const uint32_t wo = g == 0 ? w_out[0] : g == 1 ? w_out[1] : w_out[2];
+                const uint32_t wc = g == 0 ? w_symcap[0] : g == 1 ? w_symcap[1] : w_symcap[2];
+                uo.nsym = min(wo, wc);
+                uo.walk_ok = 1;
+            }
+        }
+    }
+}
+
+template <int N, bool ZB>
+static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, int cls, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS);   // per call: cheap, and right on every device
+    const unsigned groups = (unsigned)((n + LS_WAVES * LS_SPW - 1) / (LS_WAVES * LS_SPW));
+    hipLaunchKernelGGL((k_dec_tans_ls<N, ZB>), dim3(groups), dim3(64 * LS_WAVES), LS_LDS, stream, d_units,
+                       d_list + (size_t)cls * (size_t)n, d_count + cls);
+}
+
+// d_list: LS_CLASSES * n ints, d_count: LS_CLASSES ints (session workspace)
+void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t) {
+    if (t) t->mark("k_dec_classify");
+    hipLaunchKernelGGL(k_dec_classify, dim3(1), dim3(1024), 0, stream, d_units, n, d_list, d_count);
+    if (t) t->mark("k_dec_tans_ls<2,false>");
+    launch_ls_class<2, false>(d_units, n, d_list, d_count, 0, stream);
+    if (t) t->mark("k_dec_tans_ls<other>");
+    launch_ls_class<2, true>(d_units, n, d_list, d_count, 1, stream);
+    launch_ls_class<4, false>(d_units, n, d_list, d_count, 2, stream);
+    launch_ls_class<4, true>(d_units, n, d_list, d_count, 3, stream);
+    launch_ls_class<8, false>(d_units, n, d_list, d_count, 4, stream);
+    launch_ls_class<8, true>(d_units, n, d_list, d_count, 5, stream);
+}

@@ -119,3 +119,46 @@ def closed_form(n: int, mul: int = 131, add: int = 7, mod: int = 65536) -> np.nd
     (waveletu16_test.go:190-248)."""
     i = np.arange(n, dtype=np.int64)
     return ((i * mul + add) % mod).astype(np.uint16)
+
+
+def wsi_slide_band(width: int, height: int, y0: int, y1: int, seed: int = 4) -> np.ndarray:
+    """Rows [y0, y1) of wsi_slide(width, height, seed): 32-bit integer arithmetic only (a band of a 32768 x 32768 slide
+    must come out in a fraction of a second), pixel (x, y) a pure function of (x, y, width, height, seed)."""
+    yy = np.arange(y0, y1, dtype=np.int64)[:, None]
+    xx = np.arange(width, dtype=np.int64)[None, :]
+    m = min(width, height)
+    mask = np.zeros((y1 - y0, width), dtype=bool)
+    for cx, cy, r in ((0.35, 0.4, 0.28), (0.68, 0.62, 0.2)):
+        mask |= ((xx - int(cx * width)) ** 2 + (yy - int(cy * height)) ** 2) < int(r * m) ** 2
+    band = np.full((y1 - y0, width, 3), 255, dtype=np.uint8)
+    if not mask.any():
+        return band
+    with np.errstate(over="ignore"):                                    # lowbias32 hash of the pixel index
+        h = ((yy * width + xx) & 0xFFFFFFFF).astype(np.uint32) + np.uint32((seed * 0x9E3779B1) & 0xFFFFFFFF)
+        h ^= h >> np.uint32(16); h *= np.uint32(0x7FEB352D)
+        h ^= h >> np.uint32(15); h *= np.uint32(0x846CA68B)
+        h ^= h >> np.uint32(16)
+    n0 = (h & np.uint32(0xFF)).astype(np.int16) - np.int16(128)
+    n1 = ((h >> np.uint32(8)) & np.uint32(0xFF)).astype(np.int16) - np.int16(128)
+    # crossed triangle waves stand in for the stroma texture
+    tex = (((xx % 44) - 22).astype(np.int16) * ((yy % 56) - 28).astype(np.int16)) // np.int16(32)
+    chans = (np.clip(200 + tex + n0 // 10, 0, 255), np.clip(120 + (tex * 3) // 5 + n1 // 12, 0, 255),
+             np.clip(170 + (tex * 4) // 5 + n0 // 16, 0, 255))
+    for c, ch in enumerate(chans):
+        np.copyto(band[:, :, c], ch.astype(np.uint8), where=mask)
+    return band
+
+
+def wsi_slide(width: int, height: int, seed: int = 4, workers: int = 8, band_rows: int = 512) -> np.ndarray:
+    """H&E-like RGB slide for the MIC3 configuration sizes (BASELINE.json config 5: 32768 x 32768): white glass with two
+    textured, noisy tissue discs (about 37 % of the area), generated band by band on `workers` threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty((height, width, 3), dtype=np.uint8)
+
+    def fill(y0):
+        y1 = min(height, y0 + band_rows)
+        out[y0:y1] = wsi_slide_band(width, height, y0, y1, seed)
+
+    with ThreadPoolExecutor(max(1, workers)) as ex:
+        list(ex.map(fill, range(0, height, band_rows)))
+    return out

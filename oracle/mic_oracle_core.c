@@ -1093,6 +1093,7 @@ int mico_pics_decompress(const uint8_t *in, size_t len, uint16_t *px,
     *w = width; *h = height;
     if (!px) return MICO_OK;
     if ((size_t)width * (size_t)height > px_cap) return MICO_ERR_CAPACITY;
+    memset(px, 0, (size_t)width * (size_t)height * 2);           /* out := make([]uint16, width*height), parallelstrips.go:288 */
     for (int s = 0; s < num_strips; s++) {
         size_t so = get_u32(in + 20 + (size_t)s * 8), sl = get_u32(in + 24 + (size_t)s * 8);
         size_t start = header + so, end = start + sl;

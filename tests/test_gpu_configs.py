@@ -1,0 +1,115 @@
+"""GPU tests at the sizes BASELINE.json names (configs 3, 4 and 5; config 2, PICS-8 on the 2577 x 2048 XR shape, is in
+test_gpu_parity.py).  Everything goes through the C ABI and is compared with the CPU oracle on the same seeded inputs;
+the 32768 x 32768 slide is checked against the oracle on the parts the oracle does in seconds (an 8192 x 8192 slide in full,
+sampled tiles of the big one byte for byte) and through the round trip for the rest."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- config 3: WaveletV2SIMDRLEFSECompressU16, 5 levels, CR shape rows 2140 x cols 1760 (waveletfsecompressu16.go:427) ----
+def test_config3_wavelet_v2_on_cr_shape(mic, mico, synth, gpu_ready):
+    img = synth.cr_like()                                            # cols 1760, rows 2140 (fseu16_test.go:31)
+    rows, cols = img.shape
+    assert (rows, cols) == (2140, 1760)
+    rc, want = mico.wavelet_v2_compress(img, 4095, 5)
+    assert rc == 0
+    got = mic.wavelet_v2_compress(img, rows, cols, 4095, 5)
+    assert got == want
+    assert got[10] == 5 and got[11:13] == bytes([0xFF, 0x04])        # 5 levels applied, 4-state FSE, no fallback
+    px, r, c = mic.wavelet_v2_decompress(got)
+    assert (r, c) == (rows, cols) and np.array_equal(px, img)
+    rc, opx = mico.wavelet_v2_decompress(got)                        # and the oracle reads the device's file
+    assert rc == 0 and np.array_equal(opx, img)
+
+
+def test_config3_wavelet_v2_batch_of_cr_frames(mic, mico, synth, gpu_ready):
+    """Several CR-shaped frames side by side (the batch entry points): every file equals the oracle's for that frame."""
+    frames = np.stack([synth.xr_like(cols=1760, rows=2140, depth=12, seed=20 + i, noise=5.0 + 3.0 * i) for i in range(3)])
+    res = mic.wavelet_v2_compress_batch(frames, 4095, 5)
+    files = []
+    for i, (st, blob) in enumerate(res):
+        rc, want = mico.wavelet_v2_compress(frames[i], 4095, 5)
+        assert st == 0 and rc == 0 and blob == want
+        files.append(blob)
+    st, px = mic.wavelet_v2_decompress_batch(files)
+    assert st == [0, 0, 0] and np.array_equal(px.reshape(frames.shape), frames)
+
+
+# ---- config 4: MIC2 independent mode, 512 frames of 512 x 512 (multiframecompress.go:179) ---------------------------------
+def test_config4_mic2_independent_512_cubed(mic, mico, synth, gpu_ready):
+    stack = synth.ct_stack(512, 512, 12, seed=3)
+    rc, want = mico.mic2_compress(stack, 4095, False)
+    assert rc == 0
+    got = mic.compress_multi_frame(stack, 512, 512, 4095, temporal=False)
+    assert got == want
+    assert got[:4] == b"MIC2" and int.from_bytes(got[12:16], "little") == 512 and got[16] == 0x01
+    back = mic.decompress_multi_frame(got)
+    assert back.shape == stack.shape and np.array_equal(back, stack)
+    for idx in (0, 255, 511):                                        # DecompressFrame, multiframecompress.go:266
+        assert np.array_equal(mic.decompress_frame(got, idx), stack[idx])
+
+
+# ---- config 5: MIC3, 8-bit RGB, 256 x 256 tiles (wsicompress.go:27) ---------------------------------------------------
+def test_config5_wsi_8192_matches_oracle(mic, mico, synth, gpu_ready):
+    """A slide the oracle codes in a few seconds, in full: 6 pyramid levels, 1365 tiles."""
+    W = H = 8192
+    slide = synth.wsi_slide(W, H, seed=4)
+    rc, want = mico.wsi_compress(slide)
+    assert rc == 0
+    got = mic.compress_wsi(slide, W, H)
+    assert got == want
+    hdr = mic.read_wsi_header(got)
+    assert len(hdr["levels"]) == 6 and hdr["total_tiles"] == 1024 + 256 + 64 + 16 + 4 + 1
+    assert np.array_equal(mic.decompress_wsi_level(got, 0), slide)
+
+
+def _box2(a):
+    """Downsample2xRGB (wsipyramid.go:10-32)"""
+    h, w = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
+    b = a[:h, :w].astype(np.uint16)
+    return ((b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2] + 2) // 4).astype(np.uint8)
+
+
+def test_config5_wsi_32768_slide(mic, mico, synth, gpu_ready):
+    """The configuration's own size: 32768 x 32768 RGB, 8 levels, 21 845 tiles, 65 535 planes.  The file's
+    layout, the level-0 round trip, and -- against the oracle -- the bytes of sampled tile blobs on levels 0-4 (each a pure
+    function of its source pixels: compressRGBTileBlob, wsicompress.go:319-363) and the pixels of sampled tiles on every level."""
+    W = H = 32768
+    slide = synth.wsi_slide(W, H, seed=4, workers=16)
+    blob = mic.compress_wsi(slide, W, H)
+    hdr = mic.read_wsi_header(blob)
+    dims = [(l["width"], l["height"], l["tiles_x"], l["tiles_y"]) for l in hdr["levels"]]
+    assert dims == [(W >> k, H >> k, max(1, (W >> k) // 256), max(1, (H >> k) // 256)) for k in range(8)]
+    assert hdr["total_tiles"] == 21845 and (hdr["tile_width"], hdr["tile_height"]) == (256, 256)
+    c = np.frombuffer(blob, dtype=np.uint8)
+    table = 48 + 20 * 8
+    data_off = table + 16 * 21845
+    ent = c[table:data_off].view("<u8").reshape(21845, 2)
+    assert ent[0, 0] == 0 and np.array_equal(ent[1:, 0], np.cumsum(ent[:-1, 1]))       # blobs back to back, wsiformat.go:139-160
+    assert data_off + int(ent[-1, 0] + ent[-1, 1]) == len(blob)
+    first = [0, 16384, 20480, 21504, 21760, 21824, 21840, 21844]
+    rng = np.random.default_rng(7)
+    # byte parity of sampled tiles, levels 0-4: the level-k tile (tx, ty) is the 2^k-fold box reduction of a source crop
+    for k, count in ((0, 24), (1, 12), (2, 8), (3, 6), (4, 4)):
+        n = dims[k][2]
+        picks = {(int(rng.integers(n)), int(rng.integers(n))) for _ in range(count)} | {(n * 35 // 100, n * 40 // 100), (0, 0)}
+        for tx, ty in sorted(picks):
+            s = 256 << k
+            crop = slide[ty * s:(ty + 1) * s, tx * s:(tx + 1) * s]
+            for _ in range(k):
+                crop = _box2(crop)
+            rc, want = mico.wsi_compress_tile(np.ascontiguousarray(crop))
+            assert rc == 0
+            gi = first[k] + ty * n + tx
+            o, ln = int(ent[gi, 0]), int(ent[gi, 1])
+            assert bytes(c[data_off + o: data_off + o + ln]) == want, f"level {k} tile ({tx},{ty})"
+    # pixels of sampled tiles on every level, oracle reader against the device reader
+    for k in range(8):
+        n = dims[k][2]
+        for tx, ty in {(0, 0), (n - 1, n - 1), (n * 35 // 100, n * 40 // 100)}:
+            rc, t = mico.wsi_decompress_tile_at(blob, k, tx, ty)
+            assert rc == 0 and np.array_equal(mic.decompress_wsi_tile(blob, k, tx, ty), t)
+    lv0 = mic.decompress_wsi_level(blob, 0)
+    assert lv0.shape == slide.shape and np.array_equal(lv0, slide)

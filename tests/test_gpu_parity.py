@@ -135,6 +135,32 @@ def test_pics_clamp_bad_magic_truncation(mic, gpu_ready):
         mic.decompress_parallel_strips(blob[:10])                            # :97-102
 
 
+def test_pics_rows_no_strip_covers_come_back_zero(mic, mico, gpu_ready):
+    """A PICS header whose strips stop short of the image height is accepted by the reference, and the rows nobody writes
+    are the zeros of make([]uint16, w*h) (parallelstrips.go:288-320) -- not whatever an earlier call left in the staging buffer."""
+    img = _mr()[:64].copy()
+    mic.decompress_parallel_strips(mic.compress_parallel_strips(_mr(), 256, 256, int(_mr().max()), 8))   # leave pixels behind
+    blob = bytearray(mic.compress_parallel_strips(img, 256, 64, int(img.max()), 4))
+    blob[8:12] = (80).to_bytes(4, "little")                                  # height 80, 4 strips of 16 rows: rows 64-79 uncovered
+    px, w, h = mic.decompress_parallel_strips(bytes(blob))
+    assert (w, h) == (256, 80) and np.array_equal(px[:64], img) and not px[64:].any()
+    rc, want = mico.pics_decompress(bytes(blob))
+    assert rc == 0 and want.shape == (80, 256) and np.array_equal(want, px)
+
+
+def test_mic3_level_table_is_validated(mic, synth, gpu_ready):
+    """Level descriptors that are not what computeLevels writes (wsiformat.go:244-271) are refused instead of steering the tile loops."""
+    blob = bytearray(mic.compress_wsi(synth.wsi_like(300, 200, seed=3), 300, 200))
+    for off, val in ((48 + 8, 1 << 30), (48 + 12, 0), (48 + 16, 5000), (48 + 0, 0)):   # tilesX, tilesY, firstTileIdx, width of level 0
+        bad = bytearray(blob)
+        bad[off:off + 4] = int(val).to_bytes(4, "little")
+        for call in (lambda b: mic.decompress_wsi_level(b, 0), lambda b: mic.decompress_wsi_tile(b, 0, 0, 0),
+                     lambda b: mic.decompress_wsi_region(b, 0, 0, 0, 10, 10)):
+            with pytest.raises(mic.MicError) as e:
+                call(bytes(bad))
+            assert e.value.code == mic.MIC_ERR_CORRUPT
+
+
 def test_mic2_matches_oracle(mic, mico, synth, gpu_ready):
     stack = synth.ct_stack(frames=6, size=128, depth=12, seed=21)
     rc, want = mico.mic2_compress(stack, 4095, False)

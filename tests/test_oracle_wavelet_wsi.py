@@ -60,6 +60,34 @@ def test_wavelet_v2_published_ratio(mico, name, ratio):
     assert rc == 0 and np.array_equal(px, img)
 
 
+# results/20260518-054951/06-wavelet-simd.txt:13-25 -- BenchmarkWaveletV2SIMDRLEFSECompress on the NEMA images the build
+# container holds: compressed size in MiB ("comp", 4 significant digits; "original" 0.5000 = 524 288 B fixes the unit) and ratio.
+_NEMA_WAVELET = {"CT1": (512, 512, 0.2012, 2.485), "CT2": (512, 512, 0.1745, 2.865), "MR1": (512, 512, 0.2334, 2.142),
+                 "MR2": (1024, 1024, 0.5983, 3.343), "MR3": (512, 512, 0.1224, 4.086), "MR4": (512, 512, 0.1196, 4.180),
+                 "NM1": (256, 1024, 0.09970, 5.015), "XA1": (1024, 1024, 0.4048, 4.940)}
+
+
+@pytest.mark.parametrize("name", sorted(_NEMA_WAVELET))
+def test_wavelet_v2_published_nema_sizes(mico, name):
+    """The eight NEMA images: WaveletV2 (5 levels) compressed MiB and ratio equal the published figures to the
+    printed digit (size pinned to ~±50 B in 100-600 KB; bytes stay unpinned, oracle/README.md)."""
+    path = f"/root/reference/testdata/compsamples_refanddir/IMAGES/REF/{name}_UNC"
+    if not os.path.exists(path):
+        pytest.skip("NEMA inputs only exist in the build container")
+    w, h, comp_mib, ratio = _NEMA_WAVELET[name]
+    b = open(path, "rb").read()
+    i = b.rfind(bytes([0xE0, 0x7F, 0x10, 0x00]))                       # last (7FE0,0010) tag, SURVEY.md §0
+    ln = int.from_bytes(b[i + 8:i + 12], "little")
+    img = np.frombuffer(b[i + 12:i + 12 + ln], dtype="<u2")[: w * h].reshape(h, w).copy()
+    rc, blob = mico.wavelet_v2_compress(img, int(img.max()), 5)
+    assert rc == 0
+    digits = 4 - 1 - int(np.floor(np.log10(comp_mib)))                  # decimals of a 4-significant-digit figure
+    assert round(len(blob) / 2 ** 20, digits) == comp_mib
+    assert round(img.size * 2 / len(blob), 3) == ratio
+    rc, px = mico.wavelet_v2_decompress(blob)
+    assert rc == 0 and np.array_equal(px, img)
+
+
 @pytest.mark.parametrize("rows,cols,levels", [(15, 17, 2), (63, 65, 5), (130, 70, 8), (100, 3, 5)])
 def test_wavelet_v2_round_trip_odd_dims(mico, synth, rows, cols, levels):
     img = synth.xr_like(cols=cols, rows=rows, depth=12, seed=rows + cols)
