@@ -116,7 +116,7 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p);
     HIP_TRY(hipGetLastError());
     s->n_last = n;
     return MIC_OK;
@@ -238,7 +238,7 @@ int decompress_batch_locked(mic_hip_dec_job *jobs, int njobs) {
         }
         HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
-        mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr);
+        mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr, (int *)s->cls.p);
         HIP_TRY(hipGetLastError());
         s->n_last = n;
         std::vector<int32_t> st((size_t)n);
@@ -375,7 +375,7 @@ int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *
     s->fill_workspace(u, 0);
     u.tok_cap = (uint32_t)std::min<size_t>(out_cap, u.tok_cap);
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
-    mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
+    mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr, (int *)s->cls.p);
     HIP_TRY(hipGetLastError());
     s->n_last = 1;
     int32_t st = 0;
@@ -483,7 +483,7 @@ static int decode_units_of_file(const uint8_t *file, size_t file_len, const std:
         }
         HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)nb, s->stream));
-        mic_launch_decode((MicUnit *)s->units.p, nb, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), nullptr);
+        mic_launch_decode((MicUnit *)s->units.p, nb, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), nullptr, (int *)s->cls.p);
         HIP_TRY(hipGetLastError());
         s->n_last = nb;
         std::vector<int32_t> st((size_t)nb);
@@ -716,6 +716,12 @@ int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) {
     out8[4] = u.max_count; out8[5] = u.hdr_len; out8[6] = u.zero_bits; out8[7] = u.flavour;
     out8[8] = u.count; out8[9] = u.bits_off; out8[10] = (uint32_t)u.nstates_used; out8[11] = (uint32_t)u.status; out8[12] = u.nseg; out8[13] = u.nsym; out8[14] = u.seg_cap;
     for (int k = 0; k < 16; k++) out8[16 + k] = u.dbg[k];
+    return MIC_OK;
+}
+// debug probe (not in the public header): bytes of unit i's histogram slab after a *_finish (LS_DEBUG builds dump there)
+int mic_hip_debug_fetch_hist(mic_hip_session *s, int i, void *dst, size_t bytes) {
+    if (!s || i < 0 || i >= s->n_last || bytes > kSym * 4) return MIC_ERR_ARGS;
+    HIP_TRY(hipMemcpy(dst, s->h_units[(size_t)i].hist, bytes, hipMemcpyDeviceToHost));
     return MIC_OK;
 }
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {

@@ -979,7 +979,7 @@ static void launch_tans_lds(MicUnit *d_units, int n, hipStream_t stream, MicTime
     if (!ZB && n <= 1280) launch_tans_lds_class<N, false, 16>(d_units, n, stream);
 }
 
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls) {
     const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
     variant &= ~MIC_VARIANT_GRAD;
     if (variant == 100) {
@@ -989,7 +989,11 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         if (t) t->mark("k_dec_tables_wg");
         mic_launch_dec_tables(d_units, n, stream);
     }
-    if (variant != 100) {
+    if (variant == 0 && d_cls) {
+        // tableLog <= 13: lane-per-state kernels over compacted per-class lists (mic_decode_ls.hip); what they leave
+        // (bigger tables, 1-state streams, very long streams) falls through to the classes below, which skip decoded units
+        mic_launch_dec_tans_ls(d_units, n, d_cls + MIC_CLS_HEAD, d_cls, stream, t);
+    } else if (variant != 100) {
         static bool duo_attr = false;
         if (!duo_attr) {
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
@@ -1009,6 +1013,8 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         hipLaunchKernelGGL((k_dec_tans_duo<4, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
         hipLaunchKernelGGL((k_dec_tans_duo<8, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
         hipLaunchKernelGGL((k_dec_tans_duo<8, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
+    }
+    if (variant != 100) {
         launch_tans_lds<2, false>(d_units, n, stream, t, "k_dec_tans_lds<2,false,13>");
         launch_tans_lds<4, false>(d_units, n, stream, t, "k_dec_tans_lds<4,false,13>");
         launch_tans_lds<8, false>(d_units, n, stream, t, "k_dec_tans_lds<8,false,13>");

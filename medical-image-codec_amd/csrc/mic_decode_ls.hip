@@ -189,24 +189,30 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     // initial states: state 0 first, tableLog bits each (fse2state.go:210-212); kept with the +size offset
     uint32_t st = size + (window(q - (int32_t)(k * tl)) >> (32u - tl));
     q -= (int32_t)(N * tl);
-    const uint32_t mk1 = (k >= 1) ? ~0u : 0u, mk2 = (k >= 2) ? ~0u : 0u, mk4 = (k >= 4) ? ~0u : 0u;
-    // bits of a round: nb = this state's nbBits, pre = bits the earlier states of the round take, tot = the round's bits
-    auto prefix = [&](uint32_t nb, uint32_t &pre, uint32_t &tot) {
+    const uint32_t kq = k & 3u;                                             // position inside the quad (N = 8: a stream spans two quads)
+    const uint32_t mk1 = (kq >= 1) ? ~0u : 0u, mk2 = (kq >= 2) ? ~0u : 0u, mk4 = (k >= 4) ? ~0u : 0u;
+    // bits of a round: nb = this state's nbBits, pre = bits the earlier states of the round take, ntot = MINUS the round's bits.
+    // Minus, because `q - dpp(x)` must not reach the compiler: it folds the lane permutation into a v_subrev_u32_dpp, and on this
+    // toolchain (ROCm 7.2, gfx950) that instruction computes dpp(src1) - src0 instead of src1 - dpp(src0) -- measured with
+    // tools/dpp_subrev_repro.hip, v_sub_u32_dpp and v_add_u32_dpp are as documented -- so the sum is negated before it is permuted
+    // and then ADDED to the bit position.
+    auto prefix = [&](uint32_t nb, uint32_t &pre, uint32_t &ntot) {
         if (N == 2) {
             pre = ls_dpp<LS_QP(0, 0, 2, 2)>(nb) & mk1;
-            tot = nb + ls_dpp<LS_QP(1, 0, 3, 2)>(nb);
+            ntot = 0u - (nb + ls_dpp<LS_QP(1, 0, 3, 2)>(nb));
         } else {
             uint32_t t = nb + (ls_dpp<LS_QP(0, 0, 1, 2)>(nb) & mk1);
             t = t + (ls_dpp<LS_QP(0, 0, 0, 1)>(t) & mk2);                    // inclusive prefix inside the quad
-            const uint32_t tq = ls_dpp<LS_QP(3, 3, 3, 3)>(t);               // the quad's sum
-            if (N == 4) { pre = t - nb; tot = tq; }
+            const uint32_t ntq = ls_dpp<LS_QP(3, 3, 3, 3)>(0u - t);         // minus the quad's sum
+            if (N == 4) { pre = t - nb; ntot = ntq; }
             else {
-                t = t + (ls_dpp<LS_ROW_SHR(4)>(tq) & mk4);
+                t = t + ((0u - ls_dpp<LS_ROW_SHR(4)>(ntq)) & mk4);
                 pre = t - nb;
-                tot = tq + ls_dpp<LS_ROW_HALF_MIRROR>(tq);
+                ntot = ntq + ls_dpp<LS_ROW_HALF_MIRROR>(ntq);
             }
         }
     };
+    uint32_t dbg_ch = 0; (void)dbg_ch;
     // one round = N symbols of every stream of the wave; stage slot at byte offset soff from stgb
     auto round = [&](uint32_t soff) {
         const uint32_t e = entry(st);
@@ -215,21 +221,89 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
             *(ls_l16)(uintptr_t)(stgb + soff) = (uint16_t)st;
             const uint32_t c = (uint32_t)__builtin_clz(e);
             const uint32_t nb = c - C, m = C - c;                           // m = -nbBits: a funnel shift right by m mod 32 = 32 - nbBits
-            uint32_t pre, tot; prefix(nb, pre, tot);
+            uint32_t pre, ntot; prefix(nb, pre, ntot);
             const uint32_t hi1 = hi << pre;
             if (ZB) st = (uint32_t)((((uint64_t)e << 32) | hi1) >> (32u - nb));   // nbBits may be 0: a 64-bit shift by 32 is well defined
             else st = __builtin_amdgcn_alignbit(e, hi1, m);
-            q -= (int32_t)tot;
+            q += (int32_t)ntot;
         } else {
             *(ls_l16)(uintptr_t)(stgb + soff) = (uint16_t)st;
             const uint32_t c = (uint32_t)__builtin_clz(e);
             const uint32_t nb = c - C, m = C - c;
-            uint32_t pre, tot; prefix(nb, pre, tot);
+            uint32_t pre, ntot; prefix(nb, pre, ntot);
             const uint32_t hi = window(q - (int32_t)pre);                   // this state's own window
+#ifdef LS_DEBUG
+            if (dbg_ch == 0 && soff < 16u * N * 2u && lane < N && wv == 0 && blockIdx.x == 0) {
+                uint32_t *d = (uint32_t *)units[list[slot0]].hist + (soff / (N * 2u)) * 64 + k * 8;
+                d[0] = st; d[1] = nb; d[2] = pre; d[3] = (uint32_t)q; d[4] = e; d[5] = hi; d[6] = 0u - ntot; d[7] = C;
+            }
+#endif
             if (ZB) st = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
             else st = __builtin_amdgcn_alignbit(e, hi, m);
-            q -= (int32_t)tot;
+            q += (int32_t)ntot;
         }
+    };
+    // N = 2: the 64 rounds of a chunk as ONE hand-scheduled instruction stream.  A wave issues in order, so what counts is
+    // the number of issue slots between the arrival of a table entry and the issue of the next look-up:
+    //   v_ffbh, v_sub (nbBits), v_sub (-nbBits), [wait window] v_alignbit (window), v_and_dpp (partner's nbBits for the second
+    //   state), v_lshl (window past them), v_alignbit (next state), v_lshl_add (its address), ds_read_u16
+    // = 9 slots; the bit position, the next window's address and read, and the stage store go behind that read, in the
+    // shadow of its latency.  (The compiler's own order put them in front of it: 15 slots.)  The two v_sub and the window
+    // v_alignbit also cover the two wait states a DPP read of a freshly written VGPR needs.
+    // LDS queue at the top of a round: entry, window lo, window hi (in issue order).
+#define LS_ROUND_HEAD \
+        "s_waitcnt lgkmcnt(2)\n\t" \
+        "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
+        ".set ls_off, ls_off+4\n\t" \
+        "v_ffbh_u32 %[c], %[e]\n\t" \
+        "v_sub_u32 %[nb], %[c], %[C]\n\t" \
+        "v_sub_u32 %[m], %[C], %[c]\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t" \
+        "v_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
+#define LS_ROUND_LOOKUP \
+        "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\t" \
+        "ds_read_u16 %[e], %[at]\n\t"
+#define LS_ROUND_ADVANCE \
+        "v_add_u32_dpp %[pre], %[nb], %[nb] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_sub_u32 %[q], %[q], %[pre]\n\t"
+#define LS_ROUND_WINDOW \
+        "v_bfe_u32 %[at], %[q], 5, 8\n\t" \
+        "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
+        "ds_read_b32 %[w0], %[at]\n\t" \
+        "ds_read_b32 %[w1], %[at] offset:4\n\t"
+#define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_ADVANCE LS_ROUND_WINDOW
+    auto chunk2 = [&]() {
+        uint32_t e, w0, w1, c, nb, m, hi, pre, at;
+        if (ZB)                                                             // nbBits may be 0: the funnel shift would return the window
+            asm volatile(".set ls_off, 0\n\t"
+                         LS_ROUND_LOOKUP LS_ROUND_WINDOW                    // the first round's reads
+                         ".rept 64\n\t"
+                         LS_ROUND_HEAD
+                         "v_alignbit_b32 %[hi], %[e], %[hi], %[m]\n\t"
+                         "v_cmp_eq_u32 vcc, 0, %[nb]\n\t"
+                         "v_cndmask_b32 %[st], %[hi], %[e], vcc\n\t"
+                         LS_ROUND_TAIL
+                         ".endr\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb),
+                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb)
+                         : "memory", "vcc");
+        else
+            asm volatile(".set ls_off, 0\n\t"
+                         LS_ROUND_LOOKUP LS_ROUND_WINDOW                    // the first round's reads
+                         ".rept 64\n\t"
+                         LS_ROUND_HEAD
+                         "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t"
+                         LS_ROUND_TAIL
+                         ".endr\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb),
+                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb)
+                         : "memory");
     };
     // ---- RLE header walkers, one per stream (uniform values; as k_dec_tans_lds, mic_decode.hip) --------------------
     bool w_on[LS_SPW], w_err[LS_SPW]; uint32_t w_pos[LS_SPW], w_out[LS_SPW], w_nseg[LS_SPW], w_mid[LS_SPW], w_symcap[LS_SPW], w_segcap[LS_SPW], w_cnt[LS_SPW];
@@ -271,6 +345,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     uint32_t maxch = 0;
 #pragma unroll
     for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxch = max(maxch, s_chunks[j]);
+    maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);           // uniform by construction; keep the chunk loop scalar
     uint32_t pend[LS_SPW] = { 0u, 0u, 0u }; bool have_pend = false; uint32_t pch = 0;   // lane l: tokens 2l, 2l+1 of the previous chunk
     auto flush_pend = [&]() {
         if (!have_pend) return;
@@ -290,9 +365,17 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     };
     uint32_t sv_st = st; int32_t sv_q = q;                                  // a shorter stream's true state after its last whole chunk
     for (uint32_t ch = 0; ch < maxch; ch++) {
+        dbg_ch = ch;
         if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
+#ifndef LS_NO_ASM
+        if (N == 2) chunk2();
+#else
+        if (false) chunk2();
+#endif
+        else {
 #pragma unroll
-        for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
+            for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
+        }
         // the chunk's states are staged: ring upkeep, write out the previous chunk, gather this one
 #pragma unroll
         for (int j = 0; j < LS_SPW; j++) if (s_have[j]) store_blk(j, s_blk[j] - 2, pf[j]);
@@ -331,11 +414,11 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
             *(ls_l16)(uintptr_t)(stgb + r * N * 2u) = (uint16_t)st;
             const uint32_t nbr = (uint32_t)__builtin_clz(e) - C;
             const uint32_t nb = valid ? nbr : 0u;
-            uint32_t pre, tot; prefix(nb, pre, tot);
+            uint32_t pre, ntot; prefix(nb, pre, ntot);
             const uint32_t hi = window(q - (int32_t)pre);
             const uint32_t nx = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
             st = valid ? nx : st;
-            q -= (int32_t)tot;
+            q += (int32_t)ntot;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
@@ -359,7 +442,11 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     // ---- results: one lane per stream -------------------------------------------------------------------------------
     if (have && k == 0 && lane < LS_SPW * N) {
         MicUnit &uo = units[list[slot0 + (int)g]];
+#ifdef LS_DEBUG
+        if (false) {}
+#else
         if (q + 32 - (int32_t)(8u * sb) < 0) uo.status = MICD_ERR_CORRUPT;  // bitreader.go:113-120: more bits taken than the stream holds
+#endif
         else {
             uo.ntok = count;
             const bool werr = g == 0 ? w_err[0] : g == 1 ? w_err[1] : w_err[2];

@@ -23,12 +23,17 @@ struct MicTimer {
     void destroy() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); used = 0; names.clear(); }
 };
 
-// variant: 0 = default (fastest validated kernels), 100 = v0 single-lane reference kernels.
-// variant: 0 = the shipped kernels, 100 = the serial reference kernels; | MIC_VARIANT_GRAD when some unit has pred = 1 (their
+// variant: 0 = the shipped kernels, 1 = the two-streams-per-wave tANS decoder of round 1 (k_dec_tans_duo) instead of the
+// lane-per-state one, 100 = the serial reference kernels; | MIC_VARIANT_GRAD when some unit has pred = 1 (their
 // tokeniser / predictor instantiations are only launched then)
 #define MIC_VARIANT_GRAD 0x1000
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
+// d_cls: per-session scratch of MIC_CLS_INTS(n) ints for the per-class unit lists of the lane-per-state tANS decoder (mic_decode_ls.hip)
+#define MIC_CLS_HEAD 16
+#define MIC_CLS_CLASSES 6
+#define MIC_CLS_INTS(n) (MIC_CLS_HEAD + MIC_CLS_CLASSES * (size_t)(n))
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls);
+void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t);
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false);
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream);

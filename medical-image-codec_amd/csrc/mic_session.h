@@ -57,7 +57,7 @@ using namespace micapi;
 struct mic_hip_session {
     int max_units = 0; size_t max_px = 0;   // shape of the current workspace layout (see ensure)
     hipStream_t stream = nullptr;
-    DevBuf units, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
+    DevBuf units, cls, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
     DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
     std::vector<MicUnit> h_units;
     std::vector<uint64_t> h_off;
@@ -81,6 +81,7 @@ struct mic_hip_session {
         flag_stride = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
         int rc;
         if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
+        if ((rc = cls.reserve(4 * MIC_CLS_INTS(nn)))) return rc;
         if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
         if ((rc = hist.reserve(kSym * 4 * (size_t)nn))) return rc;
         if ((rc = norm.reserve(kSym * 4 * (size_t)nn))) return rc;
@@ -116,7 +117,7 @@ struct mic_hip_session {
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     void release() {
-        DevBuf *all[] = { &units, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp };
+        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp };
         for (DevBuf *b : all) b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;

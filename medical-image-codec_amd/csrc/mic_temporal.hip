@@ -149,7 +149,7 @@ int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_t
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant, nullptr, (int *)s->cls.p);
     if (n > 1) {
         mic_launch_rle_expand((MicUnit *)s->units.p, n, s->stream, 3);
         hipLaunchKernelGGL(k_tmp_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (MicUnit *)s->units.p, n, (uint32_t)npx);

@@ -367,7 +367,7 @@ int wv_decompress_frames(mic_hip_session *s, int nf, const std::vector<uint64_t>
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
     if (hipMemsetAsync(A, 0, n * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr);
+    mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr, (int *)s->cls.p);
     const WvDims d = wv_dims(rows, cols, levels);
     hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
     hipLaunchKernelGGL(k_wv_coeffs, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
