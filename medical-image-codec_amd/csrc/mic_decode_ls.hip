@@ -5,7 +5,7 @@
 //   state_k -> table entry -> (nbBits, nextState) -> bits at the running position -> state_k'
 // and decode throughput = resident streams / latency of one round of N symbols.  Two things bound it on a
 // CU: the LDS holds the 16-bit nextState tables of at most NINE streams (tableLog 13: 16 KiB each), and a wave issues one
-// instruction per ~4 cycles whatever its lanes do.  The earlier kernel (k_dec_tans_duo, mic_decode.hip) ran every lane of a
+// instruction per ~5 cycles whatever its lanes do.  The earlier kernel (k_dec_tans_duo, mic_decode.hip) ran every lane of a
 // wave through the same values -- two distinct streams per 64 lanes, N table look-ups issued one after the other -- so it
 // was bound by instructions issued per symbol and got slower with more states.  Here lane g*N + k of a wave owns state k of
 // the wave's stream g (three streams per wave, three waves per group, one group per CU):
@@ -13,12 +13,16 @@
 //     state's bits inside the round from a DPP prefix sum over the N lanes of its stream (quad_perm / row_shr: no LDS, no
 //     readlane), the bits from a funnel shift of the stream's bit window, kept in a 256-dword LDS ring;
 //   * N = 2: the 32-bit window is read at the round's start position together with the table look-ups, so a round costs one
-//     LDS round trip (~15 instructions for TWO symbols of THREE streams); N = 4 / 8: every lane reads its own window at its
-//     own bit position once the prefix sum is known: two LDS round trips for 4 / 8 symbols, so more states decode FASTER;
-//   * the lanes of a wave that own no state clone stream 0 (same addresses: LDS broadcasts), all 64 lanes share the
-//     per-chunk work: ring refill (64 dwords per stream and 128 symbols, prefetched a chunk ahead), translation of the 128
-//     staged states to symbols through the L2-resident symbol table, one coalesced 256-byte store per stream, and the RLE
-//     header walk on the tokens still in registers (rledecompressu16.go:59-85), one chunk behind the chain.
+//     LDS round trip; N = 4 / 8: every lane reads its own window at its own bit position once the prefix sum is known:
+//     two LDS round trips for 4 / 8 symbols, so more states decode FASTER;
+//   * the lanes of a wave that own no state clone stream 0 (same addresses: LDS broadcasts); all 64 lanes share the
+//     per-chunk work, which is small: ring refill (64 dwords per stream and 128 symbols, prefetched a chunk ahead) and one
+//     coalesced 256-byte store of the chunk's 128 STATES per stream.
+// The states are turned into symbols by k_dec_translate (below), not here: a symbol look-up is a 2-byte gather from a 16 KiB
+// table per stream -- 9 tables x 32 CUs overflow an XCD's 4 MiB L2, every wave-instruction touches 64 cache lines, and with
+// the gathers inside this kernel the chain waves spent 30 % of their time queueing on the CU's miss path (3200 of 11 000
+// cycles per chunk; stamps: tools/time_dec.py on an LS_STAMP build).  k_dec_translate has the table in LDS, streams the
+// states once, and walks the RLE headers (rledecompressu16.go:59-85) on tiles it already holds in LDS.
 // Streams come from a compacted per-class list (k_dec_classify), so a launch only touches the units of its class.
 // LDS per stream: ring 1024 B | mirror dword + pad 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
 #include "mic_dev.h"
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout assumes dynamic LDS at 0
     const int n_cls = *count_p;
-    const int slot0 = ((int)blockIdx.x * LS_WAVES + (int)wv) * LS_SPW;
+    const int slot0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * LS_WAVES + (int)wv) * LS_SPW);   // (wave-uniform, provably so: descriptors below)
     if (slot0 >= n_cls) return;                                             // waves share nothing and never meet at a barrier
     // ---- roles ----------------------------------------------------------------------------------------------------
     const uint32_t k = lane % N;                                            // state of the chain this lane runs
@@ -143,28 +147,34 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
     const int32_t cur0 = (int32_t)(8u * (len - 1) + (uint32_t)(31 - __clz(last)) + 8u * sb);
     const int32_t top_dw = have ? (cur0 - 1) >> 5 : -1;
     int32_t q = cur0 - 32;                                                  // window of a round = grid bits [q, q+32): its MSB is the next unread bit
-    // wave-uniform per-stream values for the shared work
-    bool s_have[LS_SPW]; uint64_t s_g[LS_SPW], s_out[LS_SPW], s_sym[LS_SPW]; int32_t s_top[LS_SPW], s_blk[LS_SPW]; uint32_t s_chunks[LS_SPW];
+    // wave-uniform per-stream values for the shared work.  The compressed stream and the output go through buffer descriptors:
+    // a block of the stream that lies (partly) outside it reads as zeros and a store behind a stream's last whole chunk is
+    // dropped by the range check, so the per-chunk upkeep below has no branch at all (a taken scalar branch costs a wave
+    // 30-45 cycles, and the compiler-predicated form of this upkeep had fifteen of them: 1700 cycles per chunk, stamped).
+    bool s_have[LS_SPW]; uint64_t s_out[LS_SPW]; int32_t s_blk[LS_SPW]; uint32_t s_chunks[LS_SPW];
+    __amdgpu_buffer_rsrc_t rs_in[LS_SPW], rs_out[LS_SPW];
 #pragma unroll
     for (int j = 0; j < LS_SPW; j++) {
         const int src = j * N;
         s_have[j] = slot0 + j < n_cls;
-        s_g[j] = ls_rl64(gaddr, src);
         s_out[j] = ls_rl64((uint64_t)(uintptr_t)u.tok, src);
-        s_sym[j] = ls_rl64((uint64_t)(uintptr_t)(u.tab_sym - size), src);  // indexed by the state with its +size offset
-        s_top[j] = (int32_t)ls_rl((uint32_t)top_dw, src);
         s_chunks[j] = ls_rl(count, src) / 128u;
         s_blk[j] = ((int32_t)ls_rl((uint32_t)q, src) >> 5) >> 6;
+        const uint32_t in_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_have[j] ? ((uint32_t)((int32_t)ls_rl((uint32_t)top_dw, src) + 1)) * 4u : 0u));
+        const uint32_t out_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_have[j] ? s_chunks[j] * 256u : 0u));
+        rs_in[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)ls_rl64(gaddr, src), 0, (int)in_bytes, 0x00020000);
+        rs_out[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)s_out[j], 0, (int)out_bytes, 0x00020000);
     }
     auto load_blk = [&](int j, int32_t b) -> uint32_t {                    // dword `lane` of block b of stream j, zero outside the stream
-        const int32_t idx = b * 64 + (int32_t)lane;
-        return (b >= 0 && idx <= s_top[j]) ? __builtin_nontemporal_load((ls_gcu32)(uintptr_t)s_g[j] + idx) : 0u;   // streamed once
+        return __builtin_amdgcn_raw_buffer_load_b32(rs_in[j], (b * 64 + (int32_t)lane) * 4, 0, 2);   // (a negative offset is out of range too); nt: streamed once
     };
+    const uint32_t mirror_sel = (lane == 0) ? 4u : 0u;
     auto store_blk = [&](int j, int32_t b, uint32_t v) {
         const uint32_t rb = (wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_RING;
-        const uint32_t slot = ((uint32_t)b & 3u) * 64u + lane;
-        *(ls_l32)(uintptr_t)(rb + slot * 4) = v;
-        if (slot == 0) *(ls_l32)(uintptr_t)(rb + 1024) = v;                 // mirror: a 2-dword read at slot 255 stays linear
+        *(ls_l32)(uintptr_t)(rb + (((uint32_t)b & 3u) * 64u + lane) * 4) = v;
+        // mirror: a 2-dword read at slot 255 stays linear.  Lane 0 writes it when the block is the ring's first, the pad dword
+        // behind it otherwise (an address select, not a branch)
+        if (lane == 0) *(ls_l32)(uintptr_t)(rb + 1028u - (((uint32_t)b & 3u) == 0u ? mirror_sel : 0u)) = v;
     };
     uint32_t pf[LS_SPW];
 #pragma unroll
@@ -212,7 +222,6 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
             }
         }
     };
-    uint32_t dbg_ch = 0; (void)dbg_ch;
     // one round = N symbols of every stream of the wave; stage slot at byte offset soff from stgb
     auto round = [&](uint32_t soff) {
         const uint32_t e = entry(st);
@@ -232,39 +241,29 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
             const uint32_t nb = c - C, m = C - c;
             uint32_t pre, ntot; prefix(nb, pre, ntot);
             const uint32_t hi = window(q - (int32_t)pre);                   // this state's own window
-#ifdef LS_DEBUG
-            if (dbg_ch == 0 && soff < 16u * N * 2u && lane < N && wv == 0 && blockIdx.x == 0) {
-                uint32_t *d = (uint32_t *)units[list[slot0]].hist + (soff / (N * 2u)) * 64 + k * 8;
-                d[0] = st; d[1] = nb; d[2] = pre; d[3] = (uint32_t)q; d[4] = e; d[5] = hi; d[6] = 0u - ntot; d[7] = C;
-            }
-#endif
             if (ZB) st = (uint32_t)((((uint64_t)e << 32) | hi) >> (32u - nb));
             else st = __builtin_amdgcn_alignbit(e, hi, m);
             q += (int32_t)ntot;
         }
     };
-    // N = 2: the 64 rounds of a chunk as ONE hand-scheduled instruction stream.  A wave issues in order, so what counts is
-    // the number of issue slots between the arrival of a table entry and the issue of the next look-up:
-    //   v_ffbh, v_sub (nbBits), v_sub (-nbBits), [wait window] v_alignbit (window), v_and_dpp (partner's nbBits for the second
-    //   state), v_lshl (window past them), v_alignbit (next state), v_lshl_add (its address), ds_read_u16
-    // = 9 slots; the bit position, the next window's address and read, and the stage store go behind that read, in the
-    // shadow of its latency.  (The compiler's own order put them in front of it: 15 slots.)  The two v_sub and the window
-    // v_alignbit also cover the two wait states a DPP read of a freshly written VGPR needs.
-    // LDS queue at the top of a round: entry, window lo, window hi (in issue order).
-#define LS_ROUND_HEAD \
-        "s_waitcnt lgkmcnt(2)\n\t" \
-        "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
-        ".set ls_off, ls_off+4\n\t" \
-        "v_ffbh_u32 %[c], %[e]\n\t" \
-        "v_sub_u32 %[nb], %[c], %[C]\n\t" \
-        "v_sub_u32 %[m], %[C], %[c]\n\t" \
-        "s_waitcnt lgkmcnt(1)\n\t" \
-        "v_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t" \
-        "v_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
+    // N = 2: the 64 rounds of a chunk as ONE hand-scheduled instruction stream.  A wave issues in order, one instruction per
+    // ~5 cycles whether it depends on its predecessor or not (tools/ubench_ls.hip), so what counts is the number of issue slots
+    // between the arrival of a table entry and the issue of the next look-up:
+    //   s_waitcnt, v_ffbh, v_sub (nbBits), v_sub (-nbBits), s_waitcnt (window), v_alignbit (window), v_and_dpp (the partner's
+    //   nbBits for the second state), v_lshl (window past them), v_alignbit (next state), v_lshl_add (its address), ds_read_u16
+    // = 11 slots + one LDS round trip (~55 cycles) = ~110 cycles per round; the stage store of the new state, the bit
+    // position and the next window's address and reads go behind that read, in the shadow of its latency.  (The compiler's
+    // own order put them in front of it: 15 slots.)  The two v_sub and the window v_alignbit also cover the two wait states
+    // a DPP read of a freshly written VGPR needs.  LDS queue at the top of a round, oldest first: entry, stage store, window lo,
+    // window hi.  Slot 0 of the stage takes the state the chunk starts from, round r stores the state it produces in slot r + 1.
 #define LS_ROUND_LOOKUP \
         "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\t" \
         "ds_read_u16 %[e], %[at]\n\t"
+#define LS_ROUND_STAGE \
+        ".if ls_off < 256\n\t" \
+        "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
+        ".endif\n\t" \
+        ".set ls_off, ls_off+4\n\t"
 #define LS_ROUND_ADVANCE \
         "v_add_u32_dpp %[pre], %[nb], %[nb] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         "v_sub_u32 %[q], %[q], %[pre]\n\t"
@@ -273,12 +272,21 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
         "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
         "ds_read_b32 %[w0], %[at]\n\t" \
         "ds_read_b32 %[w1], %[at] offset:4\n\t"
-#define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_ADVANCE LS_ROUND_WINDOW
+#define LS_ROUND_HEAD \
+        "s_waitcnt lgkmcnt(3)\n\t" \
+        "v_ffbh_u32 %[c], %[e]\n\t" \
+        "v_sub_u32 %[nb], %[c], %[C]\n\t" \
+        "v_sub_u32 %[m], %[C], %[c]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t" \
+        "v_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
+#define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_ADVANCE LS_ROUND_WINDOW
     auto chunk2 = [&]() {
         uint32_t e, w0, w1, c, nb, m, hi, pre, at;
         if (ZB)                                                             // nbBits may be 0: the funnel shift would return the window
             asm volatile(".set ls_off, 0\n\t"
-                         LS_ROUND_LOOKUP LS_ROUND_WINDOW                    // the first round's reads
+                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW     // the first round's reads, the chunk's first state
                          ".rept 64\n\t"
                          LS_ROUND_HEAD
                          "v_alignbit_b32 %[hi], %[e], %[hi], %[m]\n\t"
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
                          : "memory", "vcc");
         else
             asm volatile(".set ls_off, 0\n\t"
-                         LS_ROUND_LOOKUP LS_ROUND_WINDOW                    // the first round's reads
+                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW
                          ".rept 64\n\t"
                          LS_ROUND_HEAD
                          "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t"
@@ -305,40 +313,6 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
                          : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb)
                          : "memory");
     };
-    // ---- RLE header walkers, one per stream (uniform values; as k_dec_tans_lds, mic_decode.hip) --------------------
-    bool w_on[LS_SPW], w_err[LS_SPW]; uint32_t w_pos[LS_SPW], w_out[LS_SPW], w_nseg[LS_SPW], w_mid[LS_SPW], w_symcap[LS_SPW], w_segcap[LS_SPW], w_cnt[LS_SPW];
-    __attribute__((address_space(1))) ls_v2 *w_seg[LS_SPW];
-#pragma unroll
-    for (int j = 0; j < LS_SPW; j++) {
-        const int src = j * N;
-        const uint32_t on = (have && u.mode == 0 && u.seg != nullptr) ? 1u : 0u;
-        w_on[j] = s_have[j] && ls_rl(on, src) != 0; w_err[j] = false;
-        w_pos[j] = 0; w_out[j] = 0; w_nseg[j] = 0; w_mid[j] = 0;
-        const uint32_t sc = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);
-        w_symcap[j] = ls_rl(sc, src); w_segcap[j] = ls_rl(u.seg_cap, src); w_cnt[j] = ls_rl(count, src);
-        w_seg[j] = (__attribute__((address_space(1))) ls_v2 *)(uintptr_t)ls_rl64((uint64_t)(uintptr_t)u.seg, src);
-    }
-    auto walk = [&](int j, uint32_t cend, auto get) {                       // headers in front of token cend
-        while (w_on[j] && w_pos[j] < cend) {
-            const uint32_t hd = get(w_pos[j]);
-            if (w_pos[j] == 0) {                                            // token 0 fixes the run / literal split
-                const int d0 = mic_len16((uint16_t)hd);
-                if (d0 == 0) { w_on[j] = false; w_err[j] = true; break; }
-                w_mid[j] = (1u << (d0 - 1)) - 1; w_pos[j] = 1;
-                continue;
-            }
-            if (w_out[j] >= w_symcap[j]) { w_on[j] = false; break; }
-            if (hd == 0 || w_nseg[j] >= w_segcap[j]) { w_on[j] = false; w_err[j] = true; break; }
-            if (hd <= w_mid[j]) {
-                if (w_pos[j] + 1 >= w_cnt[j]) { w_on[j] = false; w_err[j] = true; break; }
-                if (lane == 0) { ls_v2 r; r.x = (w_pos[j] + 1) | 0x80000000u; r.y = w_out[j]; w_seg[j][w_nseg[j]] = r; }
-                w_nseg[j]++; w_out[j] += hd; w_pos[j] += 2;
-            } else {
-                if (lane == 0) { ls_v2 r; r.x = w_pos[j] + 1; r.y = w_out[j]; w_seg[j][w_nseg[j]] = r; }
-                w_nseg[j]++; w_out[j] += hd - w_mid[j]; w_pos[j] += 1 + (hd - w_mid[j]);
-            }
-        }
-    };
     // ---- chunks of 128 symbols per stream ---------------------------------------------------------------------------
     constexpr uint32_t R = 128 / N;                                         // rounds per chunk
     const uint32_t chunks = count / 128u, rem = count - chunks * 128u;
@@ -346,52 +320,47 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
 #pragma unroll
     for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxch = max(maxch, s_chunks[j]);
     maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);           // uniform by construction; keep the chunk loop scalar
-    uint32_t pend[LS_SPW] = { 0u, 0u, 0u }; bool have_pend = false; uint32_t pch = 0;   // lane l: tokens 2l, 2l+1 of the previous chunk
-    auto flush_pend = [&]() {
-        if (!have_pend) return;
-        const uint32_t cbase = pch * 128u;
-#pragma unroll
-        for (int j = 0; j < LS_SPW; j++) {
-            if (s_have[j] && pch < s_chunks[j]) {
-                const uint32_t pk = pend[j];
-                __builtin_nontemporal_store(pk, (ls_gu32)(uintptr_t)s_out[j] + pch * 64u + lane);
-                walk(j, cbase + 128u, [&](uint32_t pos) -> uint32_t {
-                    const uint32_t rel = pos - cbase;
-                    const uint32_t d = ls_rl(pk, (int)(rel >> 1));
-                    return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
-                });
-            }
-        }
-    };
     uint32_t sv_st = st; int32_t sv_q = q;                                  // a shorter stream's true state after its last whole chunk
-    for (uint32_t ch = 0; ch < maxch; ch++) {
-        dbg_ch = ch;
-        if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
-#ifndef LS_NO_ASM
-        if (N == 2) chunk2();
+#ifdef LS_STAMP
+    uint64_t stamp[4] = { 0, 0, 0, 0 }, t_prev = __builtin_amdgcn_s_memtime();
+#define LS_T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stamp[i] += t_ - t_prev; t_prev = t_; } while (0)
 #else
-        if (false) chunk2();
+#define LS_T(i) do { } while (0)
 #endif
+    for (uint32_t ch = 0; ch < maxch; ch++) {
+        if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
+        if (N == 2) chunk2();
         else {
 #pragma unroll
             for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
         }
-        // the chunk's states are staged: ring upkeep, write out the previous chunk, gather this one
+        LS_T(0);
+        // the chunk's 128 states per stream are staged: out they go (lane l: states 2l, 2l+1), and the ring moves on.
+        // Order: every consumer of last chunk's prefetch first -- the wait on the memory counter is then for operations that
+        // have had a whole chunk to complete -- then the new loads, then the stores (vmcnt counts loads and stores together, in
+        // order: a ring store behind a fresh global store would wait for that store's acknowledgement).
 #pragma unroll
-        for (int j = 0; j < LS_SPW; j++) if (s_have[j]) store_blk(j, s_blk[j] - 2, pf[j]);
-        flush_pend();
+        for (int j = 0; j < LS_SPW; j++) store_blk(j, s_blk[j] - 2, pf[j]);
+        LS_T(1);
 #pragma unroll
         for (int j = 0; j < LS_SPW; j++) {
-            if (!s_have[j]) continue;
             s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
             pf[j] = load_blk(j, s_blk[j] - 2);
-            const uint32_t s2 = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
-            const ls_gcu16 sy = (ls_gcu16)(uintptr_t)s_sym[j];
-            pend[j] = (ch < s_chunks[j]) ? ((uint32_t)sy[s2 & 0xFFFFu] | ((uint32_t)sy[s2 >> 16] << 16)) : 0u;   // (a finished stream decodes garbage: keep it off the table)
         }
-        have_pend = true; pch = ch;
+        LS_T(2);
+        {
+            uint32_t s2[LS_SPW];
+#pragma unroll
+            for (int j = 0; j < LS_SPW; j++) s2[j] = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
+#pragma unroll
+            for (int j = 0; j < LS_SPW; j++)                                // (a finished stream decodes garbage: its descriptor ends at its last whole chunk)
+                __builtin_amdgcn_raw_buffer_store_b32(s2[j], rs_out[j], (int)(ch * 256u + lane * 4u), 0, 2);
+        }
+        LS_T(3);
     }
-    flush_pend();
+#ifdef LS_STAMP
+    if (lane == 0) { MicUnit &ud = units[list[slot0]]; for (int i = 0; i < 4; i++) ud.dbg[i] = (uint32_t)(stamp[i] >> 4); ud.dbg[4] = maxch; }
+#endif
     if (chunks < maxch) { st = sv_st; q = sv_q; }                           // (per lane) back to the true end-of-chunks state
     if (maxch) {   // ... and the rings back to where those states read (the run-off moved them on); harmless for the longest stream
 #pragma unroll
@@ -426,38 +395,102 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
             if (!s_have[j]) continue;
             const uint32_t rj = ls_rl(rem, j * N), done = s_chunks[j] * 128u;
             const uint32_t s2 = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
-            const ls_gcu16 sy = (ls_gcu16)(uintptr_t)s_sym[j];
             const ls_gu16 o = (ls_gu16)(uintptr_t)s_out[j];
-            uint32_t t0 = 0, t1 = 0;
-            if (2 * lane < rj) { t0 = sy[s2 & 0xFFFFu]; o[done + 2 * lane] = (uint16_t)t0; }
-            if (2 * lane + 1 < rj) { t1 = sy[s2 >> 16]; o[done + 2 * lane + 1] = (uint16_t)t1; }
-            const uint32_t pk = t0 | (t1 << 16);
-            walk(j, w_cnt[j], [&](uint32_t pos) -> uint32_t {
-                const uint32_t rel = pos - done;
-                const uint32_t d = ls_rl(pk, (int)(rel >> 1));
-                return (rel & 1) ? (d >> 16) : (d & 0xFFFFu);
-            });
+            if (2 * lane < rj) o[done + 2 * lane] = (uint16_t)s2;
+            if (2 * lane + 1 < rj) o[done + 2 * lane + 1] = (uint16_t)(s2 >> 16);
         }
     }
     // ---- results: one lane per stream -------------------------------------------------------------------------------
     if (have && k == 0 && lane < LS_SPW * N) {
         MicUnit &uo = units[list[slot0 + (int)g]];
-#ifdef LS_DEBUG
-        if (false) {}
-#else
         if (q + 32 - (int32_t)(8u * sb) < 0) uo.status = MICD_ERR_CORRUPT;  // bitreader.go:113-120: more bits taken than the stream holds
-#endif
-        else {
-            uo.ntok = count;
-            const bool werr = g == 0 ? w_err[0] : g == 1 ? w_err[1] : w_err[2];
-            if (uo.mode == 0 && uo.seg != nullptr && !werr) {
-                uo.nseg = g == 0 ? w_nseg[0] : g == 1 ? w_nseg[1] : w_nseg[2];
-                const uint32_t wo = g == 0 ? w_out[0] : g == 1 ? w_out[1] : w_out[2];
-                const uint32_t wc = g == 0 ? w_symcap[0] : g == 1 ? w_symcap[1] : w_symcap[2];
-                uo.nsym = min(wo, wc);
-                uo.walk_ok = 1;
+        else { uo.ntok = count; uo.walk_ok = 2; }                           // tok holds STATES: k_dec_translate turns them into symbols
+    }
+}
+
+// ==========================================================================================
+// States -> symbols, and the RLE header walk.  One group of 1024 threads per unit that k_dec_tans_ls decoded (walk_ok == 2):
+// the unit's symbol table (tableSymbol of each state, <= 16 KiB) sits in LDS, waves 1-15 stream the states through it in tiles
+// of 7680 (16 bytes in, eight LDS look-ups, 16 bytes out, in place) and leave each translated tile in LDS as well, where wave 0
+// follows the linked list of RLE headers through it (rledecompressu16.go:59-85: a header <= midCount is a run of one value, a
+// larger one a literal chunk) one tile behind, from a 64-token window and v_readlane -- no dependent HBM read per header.
+// Stop and error rules are those of the walkers in mic_decode.hip: on an error the segments are dropped and k_dec_pixels_wg
+// walks the stream itself and reports it.  Units that are not frames (bare FSE, WaveletV2, residual frames) are translated only.
+#define TR_THREADS 1024
+#define TR_TILE ((TR_THREADS - 64) * 8)
+__global__ void __launch_bounds__(TR_THREADS, 8) k_dec_translate(MicUnit *units) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.walk_ok != 2) return;
+    __shared__ uint16_t s_sym[1 << LS_TL];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tile[2][TR_TILE + 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t size = 1u << u.table_log, ntok = u.ntok;
+    {
+        const uint32_t *src = (const uint32_t *)u.tab_sym;                  // 256 KiB-aligned slab
+        for (uint32_t i = tid; i < size / 2; i += TR_THREADS) ((uint32_t *)s_sym)[i] = src[i];
+    }
+    uint16_t *tok = u.tok;
+    const bool frame = u.mode == 0 && u.seg != nullptr;
+    // walker (wave 0; uniform values)
+    bool w_on = frame, w_err = false;
+    uint32_t w_pos = 0, w_out = 0, w_nseg = 0, w_mid = 0;
+    const uint32_t w_symcap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u), w_segcap = u.seg_cap;
+    typedef __attribute__((address_space(1))) ls_v2 *seg_p;
+    const seg_p w_seg = (seg_p)u.seg;
+    __syncthreads();
+    typedef uint32_t tr_v4 __attribute__((ext_vector_type(4)));
+    const uint32_t smask = size - 1;                                        // a state carries its +size offset: index = state - size
+    for (uint32_t base = 0, it = 0; base < ntok; base += TR_TILE, it++) {
+        const uint32_t tile_end = min(base + TR_TILE, ntok);
+        uint16_t *tile = s_tile[it & 1];
+        if (wave != 0) {
+            const uint32_t l = (tid - 64) * 8, i0 = base + l;
+            if (i0 + 8 <= tile_end) {
+                const tr_v4 v = __builtin_nontemporal_load((const tr_v4 *)(tok + i0));
+                tr_v4 o;
+                o.x = (uint32_t)s_sym[v.x & smask] | ((uint32_t)s_sym[(v.x >> 16) & smask] << 16);
+                o.y = (uint32_t)s_sym[v.y & smask] | ((uint32_t)s_sym[(v.y >> 16) & smask] << 16);
+                o.z = (uint32_t)s_sym[v.z & smask] | ((uint32_t)s_sym[(v.z >> 16) & smask] << 16);
+                o.w = (uint32_t)s_sym[v.w & smask] | ((uint32_t)s_sym[(v.w >> 16) & smask] << 16);
+                *(tr_v4 *)(tok + i0) = o;
+                *(tr_v4 *)(tile + l) = o;
+            } else {
+                for (uint32_t i = i0; i < tile_end; i++) { const uint16_t t = s_sym[tok[i] & smask]; tok[i] = t; tile[i - base] = t; }
             }
         }
+        __syncthreads();                                                    // tile `it` is in LDS; the walker is done with tile it - 1
+        if (wave == 0 && w_on) {
+            while (w_on && w_pos < tile_end) {
+                const uint32_t rel = w_pos - base;                          // (>= 0: a header inside an earlier tile was taken there)
+                const uint32_t wv = (rel + lane < tile_end - base) ? (uint32_t)tile[rel + lane] : 0u;
+                uint32_t j = 0;
+                while (j < 64 && w_on && w_pos < tile_end) {
+                    const uint32_t hd = ls_rl(wv, (int)j);
+                    if (w_pos == 0) {                                       // token 0 fixes the run / literal split
+                        const int d0 = mic_len16((uint16_t)hd);
+                        if (d0 == 0) { w_on = false; w_err = true; break; }
+                        w_mid = (1u << (d0 - 1)) - 1; w_pos = 1; j = 1;
+                        continue;
+                    }
+                    if (w_out >= w_symcap) { w_on = false; break; }
+                    if (hd == 0 || w_nseg >= w_segcap) { w_on = false; w_err = true; break; }
+                    uint32_t adv;
+                    if (hd <= w_mid) {
+                        if (w_pos + 1 >= ntok) { w_on = false; w_err = true; break; }
+                        if (lane == 0) { ls_v2 r; r.x = (w_pos + 1) | 0x80000000u; r.y = w_out; w_seg[w_nseg] = r; }
+                        w_nseg++; w_out += hd; adv = 2;
+                    } else {
+                        if (lane == 0) { ls_v2 r; r.x = w_pos + 1; r.y = w_out; w_seg[w_nseg] = r; }
+                        w_nseg++; w_out += hd - w_mid; adv = 1 + (hd - w_mid);
+                    }
+                    w_pos += adv; j += adv;                                 // j >= 64: the next header is outside the window
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        if (frame && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_symcap); u.walk_ok = 1; }
+        else u.walk_ok = 0;
     }
 }
 
@@ -481,4 +514,6 @@ void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, 
     launch_ls_class<4, true>(d_units, n, d_list, d_count, 3, stream);
     launch_ls_class<8, false>(d_units, n, d_list, d_count, 4, stream);
     launch_ls_class<8, true>(d_units, n, d_list, d_count, 5, stream);
+    if (t) t->mark("k_dec_translate");
+    hipLaunchKernelGGL(k_dec_translate, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
 }

@@ -1,0 +1,110 @@
+// ubench_ls.hip -- where a round of the lane-per-state tANS decoder (csrc/mic_decode_ls.hip, N = 2) spends its cycles on gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -o ubench_ls ubench_ls.hip ; run on the GPU box.  Prints shader cycles per round
+// (s_memtime, median over waves) for the shipped round and for ablations of it; the values decoded are meaningless.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+#define STREAM_BYTES 17680u
+#define TAB 1296u
+#define STAGE 1040u
+
+// V: 0 shipped round | 1 no stage store | 2 plain VALU instead of DPP | 3 no window reads | 4 bare chain (entry -> state -> entry)
+//    6 s_waitcnt only once per round (entry and window together)
+template <int V>
+__global__ void __launch_bounds__(192) k_round(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t g = lane / 2; if (g >= 3) g = 0;
+    const uint32_t k = lane & 1;
+    const uint32_t sbase = (wv * 3 + g) * STREAM_BYTES;
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t tb = ((wv * 3 + j) * STREAM_BYTES + TAB) >> 2;
+        for (uint32_t i = lane; i < 4096; i += 64) s_mem[tb + i] = ((const uint32_t *)tab)[i];
+        const uint32_t rb = ((wv * 3 + j) * STREAM_BYTES) >> 2;
+        for (uint32_t i = lane; i < 260; i += 64) s_mem[rb + i] = 0x9E3779B9u * (i + 1 + j);
+    }
+    __syncthreads();
+    const uint32_t cb = sbase + TAB - 2u * 8192u, C = 31u - 13u, ringb = sbase, stgb = sbase + STAGE + 2u * k;
+    const uint32_t mk1 = k ? ~0u : 0u;
+    uint32_t st = 8192u + ((out[0] + 17u * lane) & 8191u), q = 1u << 20;
+    uint32_t e, w0, w1, c, nb, m, hi, pre, at;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int ch = 0; ch < chunks; ch++) {
+        asm volatile(
+            ".set ls_off, 0\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            "v_bfe_u32 %[at], %[q], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            ".if %[V] != 3 && %[V] != 4\n\tds_read_b32 %[w0], %[at]\n\tds_read_b32 %[w1], %[at] offset:4\n\t.endif\n\t"
+            ".rept 64\n\t"
+            ".if %[V] == 3 || %[V] == 4\n\ts_waitcnt lgkmcnt(0)\n\t.elseif %[V] == 6\n\ts_waitcnt lgkmcnt(0)\n\t.else\n\ts_waitcnt lgkmcnt(2)\n\t.endif\n\t"
+            ".if %[V] != 1 && %[V] != 4\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.endif\n\t"
+            ".set ls_off, ls_off+4\n\t"
+            "v_ffbh_u32 %[c], %[e]\n\t"
+            "v_sub_u32 %[nb], %[c], %[C]\n\t"
+            "v_sub_u32 %[m], %[C], %[c]\n\t"
+            ".if %[V] == 4\n\t"
+            "v_alignbit_b32 %[st], %[e], %[q], %[m]\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".else\n\t"
+            ".if %[V] == 3 || %[V] == 6\n\tv_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t"
+            ".else\n\ts_waitcnt lgkmcnt(1)\n\tv_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t.endif\n\t"
+            ".if %[V] == 2\n\tv_and_b32 %[pre], %[nb], %[mk1]\n\t"
+            ".else\n\tv_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t.endif\n\t"
+            "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
+            "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".if %[V] == 2\n\tv_add_u32 %[pre], %[nb], %[nb]\n\t"
+            ".else\n\tv_add_u32_dpp %[pre], %[nb], %[nb] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t.endif\n\t"
+            "v_sub_u32 %[q], %[q], %[pre]\n\t"
+            "v_bfe_u32 %[at], %[q], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            ".if %[V] != 3\n\tds_read_b32 %[w0], %[at]\n\tds_read_b32 %[w1], %[at] offset:4\n\t.endif\n\t"
+            ".endif\n\t"
+            ".endr\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb), [m] "=&v"(m),
+              [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
+            : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [V] "n"(V)
+            : "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * 3 + wv] = t1 - t0;
+    if (st == 0xFFFFFFFFu) out[1] = st + q;
+}
+
+template <int V> int run(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int blocks, int waves, int chunks) {
+    CK(hipFuncSetAttribute((const void *)k_round<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * STREAM_BYTES));
+    hipLaunchKernelGGL(k_round<V>, dim3(blocks), dim3(64 * waves), 9 * STREAM_BYTES, 0, d_tab, d_out, chunks, d_cyc);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> c((size_t)blocks * 3);
+    CK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> v;
+    for (int b = 0; b < blocks; b++) for (int w = 0; w < waves; w++) v.push_back((double)c[(size_t)b * 3 + w] / ((double)chunks * 64.0));
+    std::sort(v.begin(), v.end());
+    printf("%-46s blocks %3d waves %d: %6.1f cycles/round (min %.1f max %.1f)\n", name, blocks, waves, v[v.size() / 2], v.front(), v.back());
+    return 0;
+}
+
+int main() {
+    // table: nextState values whose nbBits (13 - highbit) average ~5.5, like 12-bit noise at ratio ~2
+    std::vector<uint16_t> tab(8192);
+    uint32_t x = 12345;
+    for (auto &t : tab) { x = x * 1664525u + 1013904223u; const uint32_t nb = 3 + (x >> 28) % 6; t = (uint16_t)((1u << (13 - nb)) + ((x >> 8) & ((1u << (13 - nb)) - 1))); }
+    uint16_t *d_tab; uint32_t *d_out; unsigned long long *d_cyc;
+    CK(hipMalloc(&d_tab, 16384)); CK(hipMalloc(&d_out, 64)); CK(hipMalloc(&d_cyc, 8 * 3 * 1024));
+    CK(hipMemcpy(d_tab, tab.data(), 16384, hipMemcpyHostToDevice)); CK(hipMemset(d_out, 0, 64));
+    const int chunks = 400;
+    for (int blocks : {1, 256}) {
+        run<0>("shipped round", d_tab, d_out, d_cyc, blocks, 3, chunks);
+        run<0>("shipped round, one wave per CU", d_tab, d_out, d_cyc, blocks, 1, chunks);
+        run<1>("no stage store", d_tab, d_out, d_cyc, blocks, 3, chunks);
+        run<2>("plain VALU instead of DPP", d_tab, d_out, d_cyc, blocks, 3, chunks);
+        run<3>("no window reads", d_tab, d_out, d_cyc, blocks, 3, chunks);
+        run<6>("one wait per round (entry + window)", d_tab, d_out, d_cyc, blocks, 3, chunks);
+        run<4>("bare chain: entry, ffbh, 2 sub, alignbit, lshl_add", d_tab, d_out, d_cyc, blocks, 3, chunks);
+    }
+    return 0;
+}
