@@ -48,8 +48,10 @@ extern "C" {
 #define MIC_STATES_8 8
 
 /* ---- library / device ------------------------------------------------------------- */
-/* Selects the HIP device used by subsequent calls of the calling process (default 0).
- * Returns MIC_ERR_DEVICE when the device does not exist or is not gfx950. */
+/* Selects the HIP device of the DEFAULT session, i.e. of every entry point below that takes host pointers (default 0).
+ * Returns MIC_ERR_DEVICE when the device does not exist or is not gfx950.  A process that drives several GPUs -- the
+ * reference's host is ONE process (goroutines, parallelstrips.go:77-93; re-entrancy: ojph/mic_parallel.h:47-48) -- creates
+ * one session per device with mic_hip_session_create_on and uses the session entry points. */
 int mic_hip_set_device(int device);
 /* "gfx950 <n CUs> ..." style description of the active device; "" if none. */
 const char *mic_hip_device_name(void);
@@ -249,7 +251,11 @@ int mic_hip_mic1_decompress(const uint8_t *compressed, size_t compressed_len, ui
  * should use.  All pointers named d_* are device pointers. */
 typedef struct mic_hip_session mic_hip_session;
 
-int  mic_hip_session_create(mic_hip_session **s, int max_units, size_t max_px_per_unit);
+int  mic_hip_session_create(mic_hip_session **s, int max_units, size_t max_px_per_unit);   /* on the default session's device */
+/* The same on an explicit HIP device: the session's stream and workspace live there, and every call on the session makes that
+ * device current for the calling thread first, so one host process can own a session per GPU and drive them from any thread. */
+int  mic_hip_session_create_on(int device, mic_hip_session **s, int max_units, size_t max_px_per_unit);
+int  mic_hip_session_device(mic_hip_session *s);
 void mic_hip_session_destroy(mic_hip_session *s);
 
 typedef struct mic_hip_unit {
@@ -288,6 +294,26 @@ int mic_hip_session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs,
                                    const uint64_t *h_offsets, const mic_hip_unit *units, int n,
                                    uint16_t *d_pixels_out);
 int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status);
+/* WaveletV2 on device-resident frames (BASELINE config 3 as bench.py times it): nframes frames of rows x cols u16, contiguous at
+ * d_frames -> their streams WITHOUT the 11-byte file header (rows u32, cols u32, maxValue u16, levels u8,
+ * waveletfsecompressu16.go:346-350 -- the caller holds those), packed back to back in the session: *d_streams,
+ * h_offsets[nframes + 1], h_status[nframes]; *levels_applied = the level count the header carries (:321-330).  decode is the
+ * inverse for streams of one shape and level count.  Files written from these streams equal mic_hip_wavelet_v2_compress's. */
+int mic_hip_session_wavelet_v2_encode(mic_hip_session *s, const uint16_t *d_frames, int nframes, int rows, int cols, int levels,
+                                      const uint8_t **d_streams, uint64_t *h_offsets, int32_t *h_status, int *levels_applied);
+int mic_hip_session_wavelet_v2_decode(mic_hip_session *s, const uint8_t *d_streams, const uint64_t *h_offsets, int nframes,
+                                      int rows, int cols, int levels, uint16_t *d_pixels_out, int32_t *h_status);
+/* MIC3 on a device-resident slide (BASELINE config 5 as bench.py times it).  encode = CompressWSI (wsicompress.go:27-171) up
+ * to, but without, the container: pyramid, tiles, YCoCg-R, plane modes and every plane's CompressSingleFrame on the device, the
+ * coded planes kept in a store the session owns (device bytes + one host record per plane); *compressed_bytes = the size of the
+ * MIC3 file they make.  write = WriteMIC3 (wsiformat.go:99-165) around the store: the file mic_hip_wsi_compress_ex would have
+ * written, byte for byte.  decode_level = every tile of one pyramid level, from the store, into a device image of that level
+ * (width * height * channels * bytes per sample); levels = the pyramid's shape. */
+int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int width, int height, int channels, int bits_per_sample,
+                               int tile_w, int tile_h, int levels, uint64_t *total_tiles, uint64_t *compressed_bytes);
+int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len);
+int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_pixels_out, size_t out_cap);
+int mic_hip_session_wsi_levels(mic_hip_session *s, int *levels, int *widths, int *heights, int cap);
 /* Enables (1) / disables (0) per-kernel HIP-event timing of the enqueue calls. */
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled);
 /* Per-kernel device time (ms, HIP events on the session stream) of the last enqueue:

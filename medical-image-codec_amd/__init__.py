@@ -95,7 +95,9 @@ ABI_SYMBOLS = [
     "mic_hip_mic1_compress", "mic_hip_mic1_info", "mic_hip_mic1_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
-    "mic_hip_session_create", "mic_hip_session_destroy", "mic_hip_session_stream",
+    "mic_hip_session_create", "mic_hip_session_create_on", "mic_hip_session_device", "mic_hip_session_destroy", "mic_hip_session_stream",
+    "mic_hip_session_wavelet_v2_encode", "mic_hip_session_wavelet_v2_decode",
+    "mic_hip_session_wsi_encode", "mic_hip_session_wsi_write", "mic_hip_session_wsi_decode_level", "mic_hip_session_wsi_levels",
     "mic_hip_session_encode", "mic_hip_session_decode",
     "mic_hip_session_encode_enqueue", "mic_hip_session_encode_finish",
     "mic_hip_session_decode_enqueue", "mic_hip_session_decode_finish",
@@ -119,6 +121,16 @@ def lib() -> C.CDLL:
     L.mic_hip_session_stream.restype = C.c_void_p
     L.mic_hip_session_stream.argtypes = [C.c_void_p]
     L.mic_hip_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
+    L.mic_hip_session_create_on.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
+    L.mic_hip_session_device.argtypes = [C.c_void_p]
+    L.mic_hip_session_wavelet_v2_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                                    C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    L.mic_hip_session_wavelet_v2_decode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_void_p, C.POINTER(C.c_int32)]
+    L.mic_hip_session_wsi_encode.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mic_hip_session_wsi_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_session_wsi_decode_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.mic_hip_session_wsi_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.mic_hip_session_destroy.argtypes = [C.c_void_p]
     L.mic_hip_session_destroy.restype = None
     L.mic_hip_compress_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int,
@@ -627,12 +639,21 @@ class Session:
     """mic_hip_session: encode/decode units that already live in HBM.  Device pointers are
     plain integers (e.g. ``torch.Tensor.data_ptr()``); torch itself is not needed here."""
 
-    def __init__(self, max_units: int, max_px_per_unit: int):
+    def __init__(self, max_units: int, max_px_per_unit: int, device: Optional[int] = None):
+        """device = None: the default session's device (mic_hip_set_device); an int: that HIP device -- one host process can
+        hold a session per GPU (mic_hip_session_create_on)."""
         self._h = C.c_void_p()
-        rc = lib().mic_hip_session_create(C.byref(self._h), max_units, max_px_per_unit)
+        if device is None:
+            rc = lib().mic_hip_session_create(C.byref(self._h), max_units, max_px_per_unit)
+        else:
+            rc = lib().mic_hip_session_create_on(int(device), C.byref(self._h), max_units, max_px_per_unit)
         if rc:
             _raise(rc, "session_create")
         self._n = 0
+
+    @property
+    def device(self) -> int:
+        return lib().mic_hip_session_device(self._h)
 
     def close(self):
         if self._h:
@@ -693,3 +714,50 @@ class Session:
         if rc:
             _raise(rc, "session_decode_finish")
         return np.array(st[:], dtype=np.int32)
+
+    # ---- WaveletV2 on device-resident frames (waveletfsecompressu16.go:303-534) -------------------------------------------
+    def wavelet_v2_encode(self, d_frames: int, nframes: int, rows: int, cols: int, levels: int = 5):
+        """-> (device pointer of the packed header-less streams, offsets[nframes + 1], status[nframes], levels applied)"""
+        d = C.c_void_p(); offs = (C.c_uint64 * (nframes + 1))(); st = (C.c_int32 * nframes)(); ap = C.c_int(0)
+        rc = lib().mic_hip_session_wavelet_v2_encode(self._h, d_frames, nframes, rows, cols, levels, C.byref(d), offs, st, C.byref(ap))
+        if rc:
+            _raise(rc, "session_wavelet_v2_encode")
+        return d.value, np.array(offs[:], dtype=np.uint64), np.array(st[:], dtype=np.int32), ap.value
+
+    def wavelet_v2_decode(self, d_streams: int, offsets: np.ndarray, nframes: int, rows: int, cols: int, levels: int, d_pixels_out: int) -> np.ndarray:
+        offs = (C.c_uint64 * len(offsets))(*[int(v) for v in offsets]); st = (C.c_int32 * nframes)()
+        rc = lib().mic_hip_session_wavelet_v2_decode(self._h, d_streams, offs, nframes, rows, cols, levels, d_pixels_out, st)
+        if rc:
+            _raise(rc, "session_wavelet_v2_decode")
+        return np.array(st[:], dtype=np.int32)
+
+    # ---- MIC3 on a device-resident slide (wsicompress.go:27-171) ---------------------------------------------------------------
+    def wsi_encode(self, d_pixels: int, width: int, height: int, channels: int = 3, bits_per_sample: int = 8,
+                   tile_w: int = 0, tile_h: int = 0, levels: int = 0) -> Tuple[int, int]:
+        """-> (tiles, size of the MIC3 file the coded planes make); the planes stay in the session"""
+        tt = C.c_uint64(0); cb = C.c_uint64(0)
+        rc = lib().mic_hip_session_wsi_encode(self._h, d_pixels, width, height, channels, bits_per_sample, tile_w, tile_h, levels, C.byref(tt), C.byref(cb))
+        if rc:
+            _raise(rc, "session_wsi_encode")
+        self._wsi_bytes = cb.value
+        return tt.value, cb.value
+
+    def wsi_write(self) -> bytes:
+        """WriteMIC3 around the session's coded planes: the file CompressWSI returns"""
+        out = np.empty(self._wsi_bytes + 64, dtype=np.uint8); n = C.c_size_t(0)
+        rc = lib().mic_hip_session_wsi_write(self._h, out.ctypes.data, out.size, C.byref(n))
+        if rc:
+            _raise(rc, "session_wsi_write")
+        return out[: n.value].tobytes()
+
+    def wsi_levels(self) -> List[Tuple[int, int]]:
+        n = C.c_int(0); w = (C.c_int * 32)(); h = (C.c_int * 32)()
+        rc = lib().mic_hip_session_wsi_levels(self._h, C.byref(n), w, h, 32)
+        if rc:
+            _raise(rc, "session_wsi_levels")
+        return [(w[i], h[i]) for i in range(n.value)]
+
+    def wsi_decode_level(self, level: int, d_pixels_out: int, out_cap: int):
+        rc = lib().mic_hip_session_wsi_decode_level(self._h, level, d_pixels_out, out_cap)
+        if rc:
+            _raise(rc, "session_wsi_decode_level")

@@ -14,24 +14,37 @@ std::mutex g_mu;
 int g_device = 0;
 bool g_device_ok = false;
 std::string g_device_name;
+mic_hip_session g_default;   // guarded by g_mu
+
+// gfx950 or nothing: the code objects are built for that target only.  One answer per device, remembered.
+int check_device(int device) {
+    static std::mutex mu; static std::vector<int8_t> known;              // 0 unknown, 1 ok, -1 not usable
+    std::lock_guard<std::mutex> lk(mu);
+    int n = 0;
+    if (device < 0 || hipGetDeviceCount(&n) != hipSuccess || device >= n) return MIC_ERR_DEVICE;
+    if (known.size() < (size_t)n) known.resize((size_t)n, 0);
+    if (known[(size_t)device] == 0) {
+        hipDeviceProp_t p;
+        known[(size_t)device] = (hipGetDeviceProperties(&p, device) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ? 1 : -1;
+    }
+    return known[(size_t)device] == 1 ? MIC_OK : MIC_ERR_DEVICE;
+}
 
 int ensure_device() {
     if (g_device_ok) { return hipSetDevice(g_device) == hipSuccess ? MIC_OK : MIC_ERR_DEVICE; }
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || g_device >= n) return MIC_ERR_DEVICE;
+    int rc = check_device(g_device);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(g_device));
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, g_device));
-    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return MIC_ERR_DEVICE;   // code objects are gfx950 only
     char buf[256];
     snprintf(buf, sizeof buf, "%s %d CUs %.0f GiB (%s)", p.gcnArchName, p.multiProcessorCount,
              (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), p.name);
     g_device_name = buf;
     g_device_ok = true;
+    g_default.device = g_device;
     return MIC_OK;
 }
-
-mic_hip_session g_default;   // guarded by g_mu
 
 // ---- encode -------------------------------------------------------------------------------
 int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
@@ -92,6 +105,12 @@ int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t 
 int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
                            const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
     if (n <= 0) return MIC_ERR_ARGS;
+    return session_decode_enqueue_spans(s, d_blobs, h_offsets, h_offsets + 1, units, n, d_pixels_out);
+}
+
+int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *begins, const uint64_t *ends,
+                                 const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
+    if (n <= 0) return MIC_ERR_ARGS;
     size_t max_px = 0;
     for (int i = 0; i < n; i++) {
         if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
@@ -104,9 +123,9 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
     bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
-        uint64_t len = h_offsets[i + 1] - h_offsets[i];
-        if (h_offsets[i + 1] < h_offsets[i] || len > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
-        u.comp_in = d_blobs + h_offsets[i]; u.comp_len = (uint32_t)len;
+        uint64_t len = ends[i] - begins[i];
+        if (ends[i] < begins[i] || len > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
+        u.comp_in = d_blobs + begins[i]; u.comp_len = (uint32_t)len;
         u.px_out = d_pixels_out + units[i].px_offset;
         u.w = units[i].width; u.h = units[i].height;
         u.pred = (units[i].nstates & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
@@ -271,7 +290,7 @@ const char *mic_hip_version(void) { return "mic-hip 0.1 (gfx950)"; }
 int mic_hip_set_device(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (device < 0) return MIC_ERR_ARGS;
-    if (g_device_ok && device != g_device) { g_default.release(); g_default = mic_hip_session(); g_device_ok = false; }
+    if (g_device_ok && device != g_device) { (void)g_default.activate(); g_default.release(); g_default = mic_hip_session(); g_device_ok = false; }
     g_device = device;
     return ensure_device();
 }
@@ -661,30 +680,37 @@ int mic_hip_mic2_decompress_frame(const uint8_t *c, size_t len, int frame_idx, u
 }
 
 // ---- sessions ------------------------------------------------------------------------------------
-int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_per_unit) {
+int mic_hip_session_create_on(int device, mic_hip_session **out, int max_units, size_t max_px_per_unit) {
     if (!out || max_units <= 0 || max_px_per_unit == 0) return MIC_ERR_ARGS;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        int rc = ensure_device();
-        if (rc) return rc;
-    }
+    int rc = check_device(device);
+    if (rc) return rc;
     mic_hip_session *s = new mic_hip_session();
-    int rc = s->ensure(max_units, max_px_per_unit);
+    s->device = device;
+    if ((rc = s->activate())) { delete s; return rc; }
+    rc = s->ensure(max_units, max_px_per_unit);
     if (rc) { s->release(); delete s; return rc; }
     const char *v = getenv("MIC_HIP_VARIANT");
     if (v) s->variant = atoi(v);
     *out = s;
     return MIC_OK;
 }
-void mic_hip_session_destroy(mic_hip_session *s) { if (s) { s->release(); delete s; } }
+int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_per_unit) {
+    int dev;
+    { std::lock_guard<std::mutex> lk(g_mu); dev = g_device; }
+    return mic_hip_session_create_on(dev, out, max_units, max_px_per_unit);
+}
+int mic_hip_session_device(mic_hip_session *s) { return s ? s->device : -1; }
+void mic_hip_session_destroy(mic_hip_session *s) { if (s) { (void)s->activate(); s->release(); delete s; } }
 void *mic_hip_session_stream(mic_hip_session *s) { return s ? (void *)s->stream : nullptr; }
 
 int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
     if (!s || !d_pixels || !units) return MIC_ERR_ARGS;
+    { const int arc = s->activate(); if (arc) return arc; }
     return session_encode_enqueue(s, d_pixels, units, n);
 }
 int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
     if (!s || !h_offsets || !h_status) return MIC_ERR_ARGS;
+    { const int arc = s->activate(); if (arc) return arc; }
     return session_encode_finish(s, d_blobs, h_offsets, h_status, h_nstates);
 }
 int mic_hip_session_encode(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n,
@@ -696,10 +722,12 @@ int mic_hip_session_encode(mic_hip_session *s, const uint16_t *d_pixels, const m
 int mic_hip_session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
                                    const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
     if (!s || !d_blobs || !h_offsets || !units || !d_pixels_out) return MIC_ERR_ARGS;
+    { const int arc = s->activate(); if (arc) return arc; }
     return session_decode_enqueue(s, d_blobs, h_offsets, units, n, d_pixels_out);
 }
 int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status) {
     if (!s || !h_status) return MIC_ERR_ARGS;
+    { const int arc = s->activate(); if (arc) return arc; }
     return session_decode_finish(s, h_status);
 }
 int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets, const mic_hip_unit *units, int n,

@@ -138,6 +138,13 @@ __global__ void __launch_bounds__(256) k_fill_u16(uint16_t *p, size_t n, uint16_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// constant planes of a slab in one launch: grid = (chunks, planes); fill[k] = {plane index, value}
+__global__ void __launch_bounds__(256) k_fill_planes(uint16_t *planes, size_t npx, const uint2 *fill) {
+    const uint2 f = fill[blockIdx.y];
+    uint16_t *p = planes + (size_t)f.x * npx;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) p[i] = (uint16_t)f.y;
+}
+
 struct Level { int w, h, tx, ty, first; };
 
 // autoLevelCount + computeLevels (wsiformat.go:244-285) with the truncation of wsicompress.go:47-77
@@ -644,6 +651,269 @@ int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x
         memcpy(rgb_out + (size_t)r * w * bpp, box.data() + ((size_t)(y - by + r) * bw + (size_t)(x - bx)) * bpp, (size_t)w * bpp);
     if (out_w) *out_w = w;
     if (out_h) *out_h = h;
+    return MIC_OK;
+}
+
+
+}  // extern "C"
+
+// ==========================================================================================
+// MIC3 on a device-resident slide (what bench.py times for BASELINE config 5).  mic_hip_session_wsi_encode runs the pyramid, the
+// tile extraction + YCoCg-R + plane statistics and the unit codec exactly as mic_hip_wsi_compress_ex does, but the coded planes
+// never leave the device: they are appended to a store the session owns (device bytes + one host record per plane).
+// mic_hip_session_wsi_write turns the store into the MIC3 file (WriteMIC3, wsiformat.go:99-165: the only step that needs the
+// bytes on the host); mic_hip_session_wsi_decode_level decodes every tile of a level from the store into a device image.
+struct WsiPlane { uint8_t mode; uint16_t value; uint64_t off; uint32_t len; };          // mode 0 / 1: no bytes; 2: stream; 3: raw pixels
+struct mic_hip_wsi_store {
+    Mic3 fmt; std::vector<Level> lv; size_t total_tiles = 0;
+    std::vector<WsiPlane> planes;                                                       // total_tiles * fmt.planes(), tile-major
+    DevBuf bytes; size_t used = 0;
+    int append(hipStream_t st, const void *d_src, size_t n, uint64_t *off) {            // grows by copying (rare: starts at the raw size / 2)
+        if (used + n > bytes.cap) {
+            DevBuf nb;
+            int rc = nb.reserve(std::max(bytes.cap * 2, used + n));
+            if (rc) return rc;
+            if (used && hipMemcpyAsync(nb.p, bytes.p, used, hipMemcpyDeviceToDevice, st) != hipSuccess) { nb.release(); return MIC_ERR_DEVICE; }
+            if (hipStreamSynchronize(st) != hipSuccess) { nb.release(); return MIC_ERR_DEVICE; }
+            bytes.release(); bytes = nb;
+        }
+        if (n && hipMemcpyAsync((char *)bytes.p + used, d_src, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return MIC_ERR_DEVICE;
+        *off = used; used += n;
+        return MIC_OK;
+    }
+};
+
+void mic_wsi_store_free(mic_hip_wsi_store *w) { if (w) { w->bytes.release(); delete w; } }
+
+namespace {
+
+// one pyramid level into the store: as compress_level_tiles up to the unit codec, then device-to-device appends
+int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_img, const Level &L) {
+    const Mic3 &fmt = W.fmt;
+    const size_t P = (size_t)fmt.planes(), npx = (size_t)fmt.tw * fmt.th;
+    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2)));
+    DevBuf &planes = s->wsi_planes, &stats = s->wsi_stats;
+    const size_t ntl = (size_t)L.tx * L.ty;
+    int rc;
+    for (size_t t0 = 0; t0 < ntl; t0 += per) {
+        const size_t nt = std::min(per, ntl - t0);
+        if ((rc = planes.reserve(nt * P * npx * 2 + 64)) || (rc = stats.reserve(nt * P * 8 + 64))) return rc;
+        std::vector<uint32_t> st(nt * P * 2);
+        for (size_t k = 0; k < nt * P; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
+        HIP_TRY(hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream));
+        if (P == 3)
+            hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img, L.w, L.h,
+                               fmt.tw, fmt.th, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        else if (fmt.bps == 16)
+            hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint16_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint16_t *)d_img,
+                               L.w, L.h, fmt.tw, fmt.th, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        else
+            hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint8_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img,
+                               L.w, L.h, fmt.tw, fmt.th, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        std::vector<mic_hip_unit> units; std::vector<size_t> unit_plane;
+        for (size_t p = 0; p < nt * P; p++) {
+            const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
+            if (mn == mx) continue;
+            units.push_back(mic_hip_unit{ p * npx, fmt.tw, fmt.th, (uint16_t)std::max<uint32_t>(mx, 255u), 2 });   // wsicompress.go:398-402
+            unit_plane.push_back(p);
+        }
+        std::vector<uint64_t> offs(units.size() + 1, 0); std::vector<int32_t> ust(units.size()), uns(units.size());
+        const uint8_t *d_blobs = nullptr; uint64_t base = 0;
+        if (!units.empty()) {
+            if ((rc = session_encode_enqueue(s, (const uint16_t *)planes.p, units.data(), (int)units.size()))) return rc;
+            if ((rc = session_encode_finish(s, &d_blobs, offs.data(), ust.data(), uns.data()))) return rc;
+            if ((rc = W.append(s->stream, d_blobs, (size_t)offs.back(), &base))) return rc;          // every stream of the slab in one copy
+        }
+        std::vector<long> unit_of(nt * P, -1);
+        for (size_t k = 0; k < units.size(); k++) unit_of[unit_plane[k]] = (long)k;
+        for (size_t p = 0; p < nt * P; p++) {
+            WsiPlane &wp = W.planes[((size_t)L.first + t0) * P + p];
+            const uint32_t mn = st[2 * p], mx = st[2 * p + 1];
+            if (mn == mx) { wp = WsiPlane{ (uint8_t)(mn == 0 ? 0 : 1), (uint16_t)mn, 0, 0 }; continue; }
+            const long ui = unit_of[p];
+            const int32_t ustat = ust[(size_t)ui];
+            if (ustat == MIC_OK) wp = WsiPlane{ 2, 0, base + offs[(size_t)ui], (uint32_t)(offs[(size_t)ui + 1] - offs[(size_t)ui]) };
+            else if (ustat == MIC_ERR_USE_RLE || ustat == MIC_ERR_INCOMPRESSIBLE) {                     // raw fallback, :403-414
+                uint64_t o = 0;
+                if ((rc = W.append(s->stream, (uint16_t *)planes.p + p * npx, npx * 2, &o))) return rc;
+                wp = WsiPlane{ 3, 0, o, (uint32_t)(npx * 2) };
+            } else return ustat;
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));                                                    // the slab's planes are reused by the next one
+    }
+    return MIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int width, int height, int channels, int bits_per_sample,
+                               int tile_w, int tile_h, int levels, uint64_t *total_tiles, uint64_t *compressed_bytes) {
+    if (!s || !d_pixels || width <= 0 || height <= 0 || tile_w < 0 || tile_h < 0) return MIC_ERR_ARGS;
+    Mic3 fmt; fmt.channels = channels; fmt.bps = bits_per_sample; fmt.flags = 0x01 | (channels == 3 ? 0x02 : 0);
+    if (!fmt.supported()) return MIC_ERR_UNSUPPORTED;
+    if (tile_w == 0) tile_w = 256;
+    if (tile_h == 0) tile_h = 256;
+    if ((size_t)tile_w * tile_h > ((size_t)1 << 26) || levels > 32) return MIC_ERR_UNSUPPORTED;
+    int rc = s->activate();
+    if (rc) return rc;
+    if ((rc = s->ensure(1, (size_t)tile_w * tile_h))) return rc;
+    if (!s->wsi) s->wsi = new mic_hip_wsi_store();
+    mic_hip_wsi_store &W = *s->wsi;
+    fmt.w = width; fmt.h = height; fmt.tw = tile_w; fmt.th = tile_h;
+    W.fmt = fmt; W.lv = plan_levels(width, height, tile_w, tile_h, levels);
+    W.fmt.nlev = (int)W.lv.size();
+    W.total_tiles = 0;
+    for (const Level &l : W.lv) W.total_tiles += (size_t)l.tx * l.ty;
+    W.fmt.total = W.total_tiles;
+    W.planes.assign(W.total_tiles * (size_t)fmt.planes(), WsiPlane{ 0, 0, 0, 0 });
+    W.used = 0;
+    const size_t bpp = fmt.bpp();
+    if ((rc = W.bytes.reserve((size_t)width * height * bpp / 2 + (1 << 20)))) return rc;
+    // pyramid on the device (Downsample2xRGB / Downsample2xGrey, wsipyramid.go:10-55); level 0 is the caller's buffer
+    std::vector<DevBuf> &img = s->wsi_pyr;
+    if (img.size() < W.lv.size()) img.resize(W.lv.size());
+    const void *prev = d_pixels;
+    for (size_t i = 1; i < W.lv.size(); i++) {
+        if ((rc = img[i].reserve((size_t)W.lv[i].w * W.lv[i].h * bpp + 64))) return rc;
+        if (channels == 3)
+            hipLaunchKernelGGL(k_wsi_downsample, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)prev, W.lv[i - 1].w, (uint8_t *)img[i].p, W.lv[i].w, W.lv[i].h);
+        else if (bits_per_sample == 16)
+            hipLaunchKernelGGL(k_wsi_downsample_grey<uint16_t>, dim3(1024), dim3(256), 0, s->stream, (const uint16_t *)prev, W.lv[i - 1].w, (uint16_t *)img[i].p, W.lv[i].w, W.lv[i].h);
+        else
+            hipLaunchKernelGGL(k_wsi_downsample_grey<uint8_t>, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)prev, W.lv[i - 1].w, (uint8_t *)img[i].p, W.lv[i].w, W.lv[i].h);
+        prev = img[i].p;
+    }
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < W.lv.size(); i++)
+        if ((rc = store_level_tiles(s, W, i == 0 ? (const void *)d_pixels : (const void *)img[i].p, W.lv[i]))) return rc;
+    if (total_tiles) *total_tiles = W.total_tiles;
+    if (compressed_bytes) {                                                     // size of the file mic_hip_session_wsi_write would produce
+        uint64_t n = 48 + 20 * (uint64_t)W.lv.size() + 16 * (uint64_t)W.total_tiles;
+        const size_t P = (size_t)fmt.planes();
+        for (size_t t = 0; t < W.total_tiles; t++) {
+            if (P == 3) n += 12;
+            for (size_t p = 0; p < P; p++) { const WsiPlane &wp = W.planes[t * P + p]; n += wp.mode == 0 ? 1 : wp.mode == 1 ? 3 : 1 + (uint64_t)wp.len; }
+        }
+        *compressed_bytes = n;
+    }
+    return MIC_OK;
+}
+
+// WriteMIC3 (wsiformat.go:99-165) around the store: header, level table, tile table, tile blobs ([Ylen][Colen][Cglen] + planes,
+// wsicompress.go:341-363; grey: the bare plane).  One device-to-host copy of the store's bytes.
+int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!s || !out || !out_len || !s->wsi) return MIC_ERR_ARGS;
+    int rc = s->activate();
+    if (rc) return rc;
+    mic_hip_wsi_store &W = *s->wsi;
+    const size_t P = (size_t)W.fmt.planes(), nlev = W.lv.size();
+    const size_t hdr = 48 + 20 * nlev + 16 * W.total_tiles;
+    std::vector<uint8_t> host(W.used + 16);
+    if (W.used) HIP_TRY(hipMemcpy(host.data(), W.bytes.p, W.used, hipMemcpyDeviceToHost));
+    size_t total = 0;
+    std::vector<uint64_t> tlen(W.total_tiles);
+    for (size_t t = 0; t < W.total_tiles; t++) {
+        uint64_t n = (P == 3) ? 12 : 0;
+        for (size_t p = 0; p < P; p++) { const WsiPlane &wp = W.planes[t * P + p]; n += wp.mode == 0 ? 1 : wp.mode == 1 ? 3 : 1 + (uint64_t)wp.len; }
+        tlen[t] = n; total += n;
+    }
+    if (out_cap < hdr + total) return MIC_ERR_CAPACITY;
+    memset(out, 0, hdr);
+    memcpy(out, "MIC3", 4); put_u32(out + 4, 1); put_u32(out + 8, (uint32_t)W.fmt.w); put_u32(out + 12, (uint32_t)W.fmt.h);
+    put_u32(out + 16, (uint32_t)W.fmt.tw); put_u32(out + 20, (uint32_t)W.fmt.th);
+    out[24] = (uint8_t)W.fmt.channels; out[25] = 0; out[26] = (uint8_t)W.fmt.bps; out[27] = (uint8_t)W.fmt.flags;
+    out[28] = (uint8_t)nlev; out[29] = (uint8_t)(nlev >> 8);
+    put_u64(out + 32, (uint64_t)W.total_tiles);
+    for (size_t i = 0; i < nlev; i++) {
+        uint8_t *ld = out + 48 + 20 * i;
+        put_u32(ld, (uint32_t)W.lv[i].w); put_u32(ld + 4, (uint32_t)W.lv[i].h); put_u32(ld + 8, (uint32_t)W.lv[i].tx);
+        put_u32(ld + 12, (uint32_t)W.lv[i].ty); put_u32(ld + 16, (uint32_t)W.lv[i].first);
+    }
+    size_t off = 0;
+    for (size_t t = 0; t < W.total_tiles; t++) {
+        uint8_t *e = out + 48 + 20 * nlev + 16 * t;
+        put_u64(e, (uint64_t)off); put_u64(e + 8, tlen[t]);
+        uint8_t *tb = out + hdr + off, *w = tb + (P == 3 ? 12 : 0);
+        for (size_t p = 0; p < P; p++) {
+            const WsiPlane &wp = W.planes[t * P + p];
+            uint8_t *w0 = w;
+            if (wp.mode == 0) *w++ = 0;
+            else if (wp.mode == 1) { *w++ = 1; *w++ = (uint8_t)wp.value; *w++ = (uint8_t)(wp.value >> 8); }
+            else { *w++ = wp.mode; memcpy(w, host.data() + wp.off, wp.len); w += wp.len; }
+            if (P == 3) put_u32(tb + 4 * p, (uint32_t)(w - w0));
+        }
+        off += tlen[t];
+    }
+    *out_len = hdr + total;
+    return MIC_OK;
+}
+
+// every tile of one level, from the store, into a device image of the level's size (bytes per pixel as the slide's)
+int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_pixels_out, size_t out_cap) {
+    if (!s || !d_pixels_out || !s->wsi) return MIC_ERR_ARGS;
+    int rc = s->activate();
+    if (rc) return rc;
+    mic_hip_wsi_store &W = *s->wsi;
+    if (level < 0 || level >= (int)W.lv.size()) return MIC_ERR_ARGS;
+    const Mic3 &m = W.fmt;
+    const Level &L = W.lv[(size_t)level];
+    const size_t P = (size_t)m.planes(), bpp = m.bpp(), npx = (size_t)m.tw * m.th;
+    if ((size_t)L.w * L.h * bpp > out_cap) return MIC_ERR_CAPACITY;
+    const size_t ntl = (size_t)L.tx * L.ty;
+    const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2)));
+    DevBuf &planes = s->wsi_planes, &aux = s->wsi_stats;
+    for (size_t t0 = 0; t0 < ntl; t0 += per) {
+        const size_t nt = std::min(per, ntl - t0);
+        if ((rc = planes.reserve(nt * P * npx * 2 + 64))) return rc;
+        std::vector<mic_hip_unit> units; std::vector<uint64_t> begins, ends; std::vector<uint2> fills; std::vector<int4> place(nt);
+        uint16_t *dp = (uint16_t *)planes.p;
+        for (size_t k = 0; k < nt; k++) {
+            const size_t t = t0 + k; const int tx = (int)(t % (size_t)L.tx), ty = (int)(t / (size_t)L.tx);
+            place[k] = make_int4(tx * m.tw, ty * m.th, std::min(m.tw, L.w - tx * m.tw), std::min(m.th, L.h - ty * m.th));
+            for (size_t p = 0; p < P; p++) {
+                const WsiPlane &wp = W.planes[((size_t)L.first + t) * P + p];
+                const size_t plane = k * P + p;
+                if (wp.mode <= 1) fills.push_back(make_uint2((uint32_t)plane, wp.mode ? wp.value : 0u));
+                else if (wp.mode == 2) { units.push_back(mic_hip_unit{ plane * npx, m.tw, m.th, 0, 0 }); begins.push_back(wp.off); ends.push_back(wp.off + wp.len); }
+                else HIP_TRY(hipMemcpyAsync(dp + plane * npx, (const char *)W.bytes.p + wp.off, npx * 2, hipMemcpyDeviceToDevice, s->stream));
+            }
+        }
+        const size_t aux_bytes = fills.size() * sizeof(uint2) + nt * sizeof(int4) + 64;
+        if ((rc = aux.reserve(aux_bytes))) return rc;
+        int4 *d_place = (int4 *)aux.p; uint2 *d_fill = (uint2 *)((char *)aux.p + nt * sizeof(int4));
+        HIP_TRY(hipMemcpyAsync(d_place, place.data(), nt * sizeof(int4), hipMemcpyHostToDevice, s->stream));
+        if (!fills.empty()) {
+            HIP_TRY(hipMemcpyAsync(d_fill, fills.data(), fills.size() * sizeof(uint2), hipMemcpyHostToDevice, s->stream));
+            for (size_t f0 = 0; f0 < fills.size(); f0 += 65535)
+                hipLaunchKernelGGL(k_fill_planes, dim3(4, (unsigned)std::min<size_t>(65535, fills.size() - f0)), dim3(256), 0, s->stream, dp, npx, (const uint2 *)d_fill + f0);
+        }
+        if (!units.empty()) {
+            if ((rc = session_decode_enqueue_spans(s, (const uint8_t *)W.bytes.p, begins.data(), ends.data(), units.data(), (int)units.size(), dp))) return rc;
+            std::vector<int32_t> st(units.size());
+            if ((rc = session_decode_finish(s, st.data()))) return rc;
+            for (int32_t v : st) if (v != MIC_OK) return v;
+        }
+        if (P == 3)
+            hipLaunchKernelGGL(k_wsi_planes_to_rgb, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, d_pixels_out, L.w);
+        else if (m.bps == 16)
+            hipLaunchKernelGGL(k_wsi_plane_to_grey<uint16_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, (uint16_t *)d_pixels_out, L.w);
+        else
+            hipLaunchKernelGGL(k_wsi_plane_to_grey<uint8_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, d_pixels_out, L.w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return MIC_OK;
+}
+
+int mic_hip_session_wsi_levels(mic_hip_session *s, int *levels, int *widths, int *heights, int cap) {
+    if (!s || !s->wsi || !levels) return MIC_ERR_ARGS;
+    *levels = (int)s->wsi->lv.size();
+    for (int i = 0; i < *levels && i < cap; i++) { if (widths) widths[i] = s->wsi->lv[(size_t)i].w; if (heights) heights[i] = s->wsi->lv[(size_t)i].h; }
     return MIC_OK;
 }
 

@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(TR_THREADS, 8) k_dec_translate(MicUnit *units)
 
 template <int N, bool ZB>
 static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, int cls, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS);   // per call: cheap, and right on every device
+    static MicPerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS);
     const unsigned groups = (unsigned)((n + LS_WAVES * LS_SPW - 1) / (LS_WAVES * LS_SPW));
     hipLaunchKernelGGL((k_dec_tans_ls<N, ZB>), dim3(groups), dim3(64 * LS_WAVES), LS_LDS, stream, d_units,
                        d_list + (size_t)cls * (size_t)n, d_count + cls);

@@ -724,8 +724,8 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W);
     if (any_grad) {
         if (t) t->mark("k_dec_predict_grad");
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dec_predict_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (PR_MAX_W + 2 * PG_Q) * 2); attr_done = true; }
+        static MicPerDeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_predict_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (PR_MAX_W + 2 * PG_Q) * 2);
         hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - 2 * PG_Q);
         hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), (PR_MAX_W + 2 * PG_Q) * 2, stream, d_units, 8192 - 2 * PG_Q, PR_MAX_W);
     }

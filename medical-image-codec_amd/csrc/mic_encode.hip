@@ -1147,13 +1147,12 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         mic_launch_enc_tables(d_units, n, stream);
     }
     if (variant != 100) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static MicPerDeviceOnce once;
+        if (once.first()) {
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_done = true;
         }
         if (t) t->mark("k_enc_tans_wg<13>");
         hipLaunchKernelGGL(k_enc_tans_wg<13>, dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);

@@ -1,8 +1,24 @@
 // mic_launch.h -- launcher interface between mic_api.hip and the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <vector>
 #include "mic_dev.h"
+
+// Kernel attributes (opt-in dynamic LDS) are per device, and launches come from any thread: true exactly when the calling thread's
+// current device has not run `setup` yet.  A second thread may see true for the same device while the first is still at it -- the
+// attribute calls are idempotent, so that is harmless.
+struct MicPerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return true;
+        const uint64_t bit = 1ull << (d & 63);
+        if (mask.load(std::memory_order_acquire) & bit) return false;
+        mask.fetch_or(bit, std::memory_order_acq_rel);
+        return true;
+    }
+};
 
 // Optional per-kernel timing: when enabled the launchers drop a HIP event on the launch
 // stream in front of every kernel (and one at the end); mic_hip_session_last_timings turns

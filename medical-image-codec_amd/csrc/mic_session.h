@@ -31,6 +31,7 @@ extern int g_device;
 extern bool g_device_ok;
 extern std::string g_device_name;
 int ensure_device();
+int check_device(int device);      // MIC_OK when `device` exists and is gfx950 (cached per device)
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -54,11 +55,21 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace micapi
 using namespace micapi;
 
+struct mic_hip_wsi_store;                       // MIC3 store of a device-resident slide (mic_api_ext.hip)
+void mic_wsi_store_free(mic_hip_wsi_store *w);
+
 struct mic_hip_session {
+    int device = 0;                         // the HIP device this session's stream and workspace live on (mic_hip_session_create_on)
     int max_units = 0; size_t max_px = 0;   // shape of the current workspace layout (see ensure)
     hipStream_t stream = nullptr;
+    // Entry points may be called from any OS thread (cgo: any goroutine's thread), and a process may hold sessions on several
+    // devices: every public call makes the session's device the calling thread's current one first.
+    int activate() { return hipSetDevice(device) == hipSuccess ? MIC_OK : MIC_ERR_DEVICE; }
     DevBuf units, cls, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
     DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
+    DevBuf wv_a, wv_b;                     // WaveletV2 coefficient planes (int32, two per frame of the batch)
+    mic_hip_wsi_store *wsi = nullptr;      // mic_hip_session_wsi_*: coded planes of a slide, on the device
+    DevBuf wsi_planes, wsi_stats; std::vector<DevBuf> wsi_pyr;
     std::vector<MicUnit> h_units;
     std::vector<uint64_t> h_off;
     int n_last = 0;
@@ -117,8 +128,11 @@ struct mic_hip_session {
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     void release() {
-        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp };
+        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
         for (DevBuf *b : all) b->release();
+        for (DevBuf &b : wsi_pyr) b.release();
+        wsi_pyr.clear();
+        if (wsi) { mic_wsi_store_free(wsi); wsi = nullptr; }
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         timer.destroy();
@@ -132,6 +146,9 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
 int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates);
 int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
                            const mic_hip_unit *units, int n, uint16_t *d_pixels_out);
+// the same with an explicit byte range [begins[i], ends[i]) of d_base per unit (streams that do not lie back to back)
+int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_base, const uint64_t *begins, const uint64_t *ends,
+                                 const mic_hip_unit *units, int n, uint16_t *d_pixels_out);
 int session_decode_finish(mic_hip_session *s, int32_t *h_status);
 size_t unit_ws_bytes(size_t px);
 // MIC2 temporal pipeline (mic_temporal.hip)
@@ -144,7 +161,10 @@ inline size_t workspace_budget() {
     static const size_t v = [] {
         const char *e = getenv("MIC_HIP_WS_BUDGET_MB");
         const long mb = e ? atol(e) : 0;
-        return mb > 0 ? (size_t)mb << 20 : (size_t)24 << 30;
+        if (mb > 0) return (size_t)mb << 20;
+        size_t fr = 0, tot = 0;                                            // a quarter of the device (72 GiB of an MI355X's 288), at least 8 GiB
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)96 << 30;
+        return std::max<size_t>(tot / 4, (size_t)8 << 30);
     }();
     return v;
 }

@@ -313,15 +313,19 @@ namespace {
 
 // nf frames of rows x cols, contiguous on the device in s->io_px: forward transform, symbols, RLE + 4-state FSE in one batch.
 // blobs[i] receives frame i's FSE stream (without the 11-byte header), st[i] its status.
-int wv_compress_frames(mic_hip_session *s, int nf, int rows, int cols, int applied, std::vector<std::vector<uint8_t>> &blobs, std::vector<int32_t> &st) {
+// d_src: the frames on the device.  blobs == nullptr: the streams stay on the device (session_encode_finish's packed buffer:
+// *d_blobs_out / offs_out), nothing is copied to the host.
+int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int rows, int cols, int applied,
+                       std::vector<std::vector<uint8_t>> *blobs, std::vector<int32_t> &st,
+                       const uint8_t **d_blobs_out = nullptr, uint64_t *offs_out = nullptr) {
     const size_t n = (size_t)rows * (size_t)cols;
     int rc;
     if ((rc = s->ensure(nf, 2 * n + 16))) return rc;                     // room for 3-word escapes
-    DevBuf a, b;
-    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) { a.release(); b.release(); return rc; }
-    auto done = [&](int code) { a.release(); b.release(); return code; };
+    DevBuf &a = s->wv_a, &b = s->wv_b;                                   // coefficient planes: kept by the session (no hipMalloc per call)
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
+    auto done = [&](int code) { return code; };
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
-    hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const uint16_t *)s->io_px.p, A, n * (size_t)nf);
+    hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
     { int r = rows, c = cols;
       for (int l = 0; l < applied; l++) {
           hipLaunchKernelGGL(k_wv_fwd_rows, dim3(grid_for((size_t)r * c), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, c, cols, n);
@@ -343,25 +347,31 @@ int wv_compress_frames(mic_hip_session *s, int nf, int rows, int cols, int appli
     std::vector<uint64_t> offs((size_t)nf + 1); std::vector<int32_t> ns((size_t)nf); const uint8_t *d_blobs = nullptr;
     st.assign((size_t)nf, 0);
     if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data()))) return done(rc);
+    if (!blobs) {
+        if (d_blobs_out) *d_blobs_out = d_blobs;
+        if (offs_out) memcpy(offs_out, offs.data(), sizeof(uint64_t) * ((size_t)nf + 1));
+        return done(MIC_OK);
+    }
     std::vector<uint8_t> host((size_t)offs[(size_t)nf] + 16);
     if (offs[(size_t)nf] && hipMemcpy(host.data(), d_blobs, (size_t)offs[(size_t)nf], hipMemcpyDeviceToHost) != hipSuccess) return done(MIC_ERR_DEVICE);
-    blobs.assign((size_t)nf, std::vector<uint8_t>());
-    for (int i = 0; i < nf; i++) if (st[(size_t)i] == MIC_OK) blobs[(size_t)i].assign(host.begin() + (long)offs[(size_t)i], host.begin() + (long)offs[(size_t)i + 1]);
+    blobs->assign((size_t)nf, std::vector<uint8_t>());
+    for (int i = 0; i < nf; i++) if (st[(size_t)i] == MIC_OK) (*blobs)[(size_t)i].assign(host.begin() + (long)offs[(size_t)i], host.begin() + (long)offs[(size_t)i + 1]);
     return done(MIC_OK);
 }
 
 // nf FSE streams (already in s->io_comp at offs[i] .. offs[i + 1]) of frames of one shape -> pixels in s->io_px
-int wv_decompress_frames(mic_hip_session *s, int nf, const std::vector<uint64_t> &offs, int rows, int cols, int levels, std::vector<int32_t> &st) {
+int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_dst, int nf, const uint64_t *offs, int rows, int cols, int levels,
+                         std::vector<int32_t> &st) {
     const size_t n = (size_t)rows * (size_t)cols;
     int rc;
     if ((rc = s->ensure(nf, 2 * n + 16))) return rc;
-    DevBuf a, b;
-    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) { a.release(); b.release(); return rc; }
-    auto done = [&](int code) { a.release(); b.release(); return code; };
+    DevBuf &a = s->wv_a, &b = s->wv_b;
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
+    auto done = [&](int code) { return code; };
     s->h_units.assign((size_t)nf, MicUnit{});
     for (int i = 0; i < nf; i++) {
         MicUnit &u = s->h_units[(size_t)i];
-        u.comp_in = (const uint8_t *)s->io_comp.p + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1;
+        u.comp_in = d_comp + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1;
         s->fill_workspace(u, i);
     }
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
@@ -376,7 +386,7 @@ int wv_decompress_frames(mic_hip_session *s, int nf, const std::vector<uint64_t>
         hipLaunchKernelGGL(k_wv_inv_cols, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n);
         hipLaunchKernelGGL(k_wv_inv_rows, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, cc, cols, n);
     }
-    hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, (uint16_t *)s->io_px.p, n * (size_t)nf);
+    hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
     s->n_last = nf;
     st.assign((size_t)nf, 0);
@@ -422,7 +432,7 @@ int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int r
         if ((rc = s->io_px.reserve(n * 2 * (size_t)nf + 64))) return rc;
         HIP_TRY(hipMemcpyAsync(s->io_px.p, frames + f0 * n, n * 2 * (size_t)nf, hipMemcpyHostToDevice, s->stream));
         std::vector<std::vector<uint8_t>> blobs; std::vector<int32_t> st;
-        if ((rc = wv_compress_frames(s, nf, rows, cols, applied, blobs, st))) return rc;
+        if ((rc = wv_compress_frames(s, (const uint16_t *)s->io_px.p, nf, rows, cols, applied, &blobs, st))) return rc;
         for (int i = 0; i < nf; i++) {
             uint8_t *o = out + (f0 + (size_t)i) * out_stride;
             status[f0 + (size_t)i] = st[(size_t)i]; out_lens[f0 + (size_t)i] = 0;
@@ -495,7 +505,7 @@ int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_
             HIP_TRY(hipMemcpyAsync((uint8_t *)s->io_comp.p + offs[(size_t)slot[(size_t)i]], files[f0 + (size_t)i] + 11, lens[f0 + (size_t)i] - 11,
                                    hipMemcpyHostToDevice, s->stream));
         std::vector<int32_t> st;
-        if ((rc = wv_decompress_frames(s, good, offs, rows, cols, levels, st))) return rc;
+        if ((rc = wv_decompress_frames(s, (const uint8_t *)s->io_comp.p, (uint16_t *)s->io_px.p, good, offs.data(), rows, cols, levels, st))) return rc;
         for (int i = 0; i < nf; i++) if (slot[(size_t)i] >= 0) {
             const size_t k = (size_t)slot[(size_t)i];
             status[f0 + (size_t)i] = st[k];
@@ -513,6 +523,40 @@ int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels
     int32_t st = 0;
     const int rc = mic_hip_wavelet_v2_decompress_batch(&c, &len, 1, pixels_out, out_cap_px, &st);
     return rc ? rc : st;
+}
+
+// ---- device-resident forms (what bench.py times for BASELINE config 3): frames, streams and pixels stay in HBM ----------------
+// nframes frames of rows x cols u16, contiguous at d_frames -> their WaveletV2 streams WITHOUT the 11-byte file header (rows, cols,
+// maxValue, levels: the caller has them), packed back to back on the device: *d_streams, h_offsets[nframes + 1], h_status[nframes];
+// *levels_applied = the level count the header would carry (waveletfsecompressu16.go:321-330).
+int mic_hip_session_wavelet_v2_encode(mic_hip_session *s, const uint16_t *d_frames, int nframes, int rows, int cols, int levels,
+                                      const uint8_t **d_streams, uint64_t *h_offsets, int32_t *h_status, int *levels_applied) {
+    if (!s || !d_frames || !d_streams || !h_offsets || !h_status || nframes <= 0 || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
+    const size_t n = (size_t)rows * (size_t)cols;
+    if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
+    if (levels < 1) levels = 1;
+    if (levels > 8) levels = 8;
+    int applied = 0;
+    { int r = rows, c = cols; for (; applied < levels; applied++) { if (r < 2 || c < 2) break; r = (r + 1) / 2; c = (c + 1) / 2; } }
+    if (levels_applied) *levels_applied = applied;
+    int rc = s->activate();
+    if (rc) return rc;
+    std::vector<int32_t> st;
+    if ((rc = wv_compress_frames(s, d_frames, nframes, rows, cols, applied, nullptr, st, d_streams, h_offsets))) return rc;
+    for (int i = 0; i < nframes; i++) h_status[i] = st[(size_t)i];
+    return MIC_OK;
+}
+// The inverse: nframes header-less streams at d_streams + h_offsets[i] (all of one shape / level count) -> pixels at d_pixels_out.
+int mic_hip_session_wavelet_v2_decode(mic_hip_session *s, const uint8_t *d_streams, const uint64_t *h_offsets, int nframes,
+                                      int rows, int cols, int levels, uint16_t *d_pixels_out, int32_t *h_status) {
+    if (!s || !d_streams || !h_offsets || !d_pixels_out || !h_status || nframes <= 0 || rows <= 0 || cols <= 0 || levels < 0 || levels > 8) return MIC_ERR_ARGS;
+    if ((size_t)rows * (size_t)cols > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
+    int rc = s->activate();
+    if (rc) return rc;
+    std::vector<int32_t> st;
+    if ((rc = wv_decompress_frames(s, d_streams, d_pixels_out, nframes, h_offsets, rows, cols, levels, st))) return rc;
+    for (int i = 0; i < nframes; i++) h_status[i] = st[(size_t)i];
+    return MIC_OK;
 }
 
 }  // extern "C"

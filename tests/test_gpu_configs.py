@@ -113,3 +113,49 @@ def test_config5_wsi_32768_slide(mic, mico, synth, gpu_ready):
             assert rc == 0 and np.array_equal(mic.decompress_wsi_tile(blob, k, tx, ty), t)
     lv0 = mic.decompress_wsi_level(blob, 0)
     assert lv0.shape == slide.shape and np.array_equal(lv0, slide)
+
+
+# ---- the device-resident forms bench.py times (inputs, streams and pixels stay in HBM) ------------------------------------
+def test_session_wavelet_v2_device_resident(mic, mico, synth, gpu_ready):
+    torch = pytest.importorskip("torch")
+    frames = np.stack([synth.xr_like(cols=1760, rows=2140, depth=12, seed=30 + i, noise=5.0) for i in range(2)])
+    d_px = torch.from_numpy(frames.view(np.int16).copy()).cuda()
+    d_out = torch.zeros_like(d_px)
+    sess = mic.Session(2, 2 * 2140 * 1760 + 16, device=0)               # mic_hip_session_create_on
+    assert sess.device == 0
+    d_streams, offs, st, applied = sess.wavelet_v2_encode(d_px.data_ptr(), 2, 2140, 1760, 5)
+    assert (st == 0).all() and applied == 5
+    packed = torch.empty(int(offs[-1]), dtype=torch.uint8, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(d_streams), ctypes.c_size_t(int(offs[-1])), 3) == 0   # device to device
+    host = packed.cpu().numpy().tobytes()
+    for i in range(2):
+        rc, want = mico.wavelet_v2_compress(frames[i], 4095, 5)
+        hdr = (2140).to_bytes(4, "little") + (1760).to_bytes(4, "little") + (4095).to_bytes(2, "little") + bytes([applied])
+        assert rc == 0 and hdr + host[int(offs[i]):int(offs[i + 1])] == want
+    st = sess.wavelet_v2_decode(packed.data_ptr(), offs, 2, 2140, 1760, applied, d_out.data_ptr())
+    assert (st == 0).all() and torch.equal(d_out, d_px)
+    sess.close()
+
+
+def test_session_wsi_device_resident(mic, mico, synth, gpu_ready):
+    torch = pytest.importorskip("torch")
+    W, H = 2304, 1800                                                    # 4 levels, ragged edge tiles, white + tissue + constant planes
+    slide = synth.wsi_slide(W, H, seed=11)
+    d_px = torch.from_numpy(slide).cuda()
+    sess = mic.Session(1, 256 * 256)
+    tiles, nbytes = sess.wsi_encode(d_px.data_ptr(), W, H)
+    rc, want = mico.wsi_compress(slide)
+    assert rc == 0 and nbytes == len(want)
+    assert sess.wsi_write() == want                                      # the container around the device-resident planes
+    assert mic.compress_wsi(slide, W, H) == want
+    lv = sess.wsi_levels()
+    assert lv[0] == (W, H) and tiles == sum(((w + 255) // 256) * ((h + 255) // 256) for w, h in lv)
+    img = slide
+    for k, (w, h) in enumerate(lv):
+        d_out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        sess.wsi_decode_level(k, d_out.data_ptr(), d_out.numel())
+        assert np.array_equal(d_out.cpu().numpy(), img), f"level {k}"
+        img = _box2(img)
+    sess.close()
