@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- PICS-8 encode+decode of XR-shaped 16-bit frames on MI355X.
+"""bench.py -- PICS-8 encode+decode of XR-shaped 16-bit frames on MI355X, plus the other BASELINE.json configurations.
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 it is launched
-through torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 it is launched through
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): a batch of synthetic XR-like frames of the reference's
-XR shape (cols 2577 x rows 2048, fseu16_test.go:32), each coded as PICS with 8 strips
-(CompressParallelStrips(..., numStrips=8)).  One step = encode the whole batch, then decode
-it again, with the frames already resident in HBM and the results left in HBM.  Strips are
-independent, so each GPU codes its own batch (weak scaling, no data-path collective).
+Headline (BASELINE.json configs[1]): a batch of DISTINCT synthetic XR-like frames of the reference's XR shape (cols 2577 x
+rows 2048, fseu16_test.go:32), noise tuned so that PICS-8 codes them at the reference's published XR ratio (~1.755), each coded
+as PICS with 8 strips (CompressParallelStrips(..., numStrips=8)).  One step = encode the whole batch, then decode it again, with
+the frames already resident in HBM and the results left in HBM.  Strips are independent, so each GPU codes its own batch (weak
+scaling, no data-path collective); for N > 1 the assembly of rank 0's view of all streams (sizes all-gather + device-to-device
+gather over RCCL) is timed separately under "container_assembly".
 
 value        = raw u16 bytes of the batch (all ranks) / time of one encode+decode step.
-roofline     = dominant kernel: algorithmic bytes (raw + compressed) per launch
-               / its mean HIP-event duration on the session stream, against 8 TB/s HBM.
+roofline     = dominant kernel: algorithmic bytes (raw + compressed of one direction) per launch / its mean
+               HIP-event duration on the session stream, against 8 TB/s HBM.
+legs         = the same measurement for BASELINE configs 3 (WaveletV2 on CR-shaped frames), 4 (MIC2, 512 frames of 512 x 512)
+               and 5 (MIC3, 32768 x 32768 RGB, 256 x 256 tiles), device-resident, each with its own roofline block (N = 1 only).
+batch_sweep  = the headline at B in {1, 64, 288, 512} frames per launch, kernel time.
 cpu_baseline = the reference's own C codec (ojph/mic_compress_c.c + mic_decompress_c.c, built in place into
-               oracle/_ref/libmic_ref.so; kind "reference") coding the strips of the same frames on the host
-               cores, one strip per thread (the mic_parallel.c model); the CPU oracle (kind "port") is timed the
-               same way and reported beside it, and stands in when the reference build is not there.
+               oracle/_ref/libmic_ref.so; kind "reference") coding the strips of one of the frames on the host cores, one
+               strip per thread (the mic_parallel.c model); the CPU oracle (kind "port") is timed the same way beside it.
 """
 import argparse
 import importlib
@@ -104,7 +107,176 @@ def cpu_baseline(mico, img, maxv, strips, budget_s=12.0, ref=None):
     who = "reference C codec (ojph/mic_compress_c.c two-state, mic_decompress_two_state_simd)" if ref is not None else "oracle (C port of the Go path)"
     return {"value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores, "kind": "reference" if ref is not None else "port",
             "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
-            "sample": f"{reps} x encode+decode of the {len(parts)} strips of one {w}x{h} frame, {who}, one strip per thread"}
+            "sample": f"{reps} x encode+decode of the {len(parts)} strips of one {w}x{h} frame, {who}, one strip per thread ({cores} threads)"}
+
+
+def roofline_block(kmean, raw_bytes, comp_bytes, traffic=None):
+    """dominant kernel of a leg against the HBM roofline: algorithmic bytes of ONE direction (raw + compressed) / its duration"""
+    if not kmean:
+        return None
+    dom = max(kmean, key=kmean.get)
+    alg = raw_bytes + comp_bytes
+    ach = alg / (kmean[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+            "kernel_ms": round(kmean[dom], 4)}
+
+
+def mean_timings(runs):
+    kt = {}
+    for t in runs:
+        for name, ms in t:
+            kt.setdefault(name, []).append(ms)
+    return {k: float(np.mean(v)) for k, v in kt.items()}
+
+
+def unit_codec_leg(mic, torch, d_px, units, steps, warmup, what):
+    """encode + decode of a unit batch through a session; returns the leg's result dict"""
+    n_units = len(units)
+    max_px = max(u[1] * u[2] for u in units)
+    sess = mic.Session(n_units, max_px)
+    cunits = mic.Session.make_units(units)
+    d_out = torch.empty_like(d_px)
+
+    def step(timing=False):
+        sess.set_timing(timing)
+        sess.encode_enqueue(d_px.data_ptr(), cunits)
+        te = sess.last_timings() if timing else []
+        d_blobs, offs, st, _ = sess.encode_finish()
+        assert (st == 0).all(), f"{what}: encode status {st[st != 0][:4]}"
+        sess.decode_enqueue(d_blobs, offs, cunits, d_out.data_ptr())
+        td = sess.last_timings() if timing else []
+        dst = sess.decode_finish()
+        assert (dst == 0).all(), f"{what}: decode status {dst[dst != 0][:4]}"
+        return offs, te + td
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        offs, _ = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    assert torch.equal(d_out, d_px), f"{what}: round trip differs"
+    kmean = mean_timings([step(True)[1] for _ in range(2)])
+    sess.close()
+    raw = d_px.numel() * 2
+    comp = int(offs[-1])
+    enc_ms = sum(v for k, v in kmean.items() if k.startswith("k_enc") or k.startswith("k_scan"))
+    dec_ms = sum(v for k, v in kmean.items() if k.startswith("k_dec"))
+    return {"value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "ratio": round(raw / comp, 4),
+            "raw_bytes": raw, "units": n_units,
+            "encode_GBps_kernels": round(raw / (enc_ms * 1e-3) / 1e9, 4) if enc_ms else None,
+            "decode_GBps_kernels": round(raw / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
+            "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02},
+            "roofline": roofline_block(kmean, raw, comp)}, kmean, offs
+
+
+def leg_wavelet(mic, torch, synth, dev, steps, warmup, nframes=48):
+    """BASELINE config 3: WaveletV2SIMDRLEFSECompressU16, 5 levels, CR shape rows 2140 x cols 1760, frames side by side"""
+    rows, cols = 2140, 1760
+    d_px = synth.xr_like_batch_torch(nframes, cols=cols, rows=rows, depth=12, seed0=2000, noise=5.0, device=dev)   # = synth.cr_like noise
+    d_out = torch.empty_like(d_px)
+    sess = mic.Session(nframes, 2 * rows * cols + 16)
+
+    def step(timing=0):
+        sess.set_timing(timing)
+        d_s, offs, st, applied = sess.wavelet_v2_encode(d_px.data_ptr(), nframes, rows, cols, 5)
+        te = sess.last_timings() if timing else []
+        assert (st == 0).all() and applied == 5
+        sess.set_timing(timing)
+        dst = sess.wavelet_v2_decode(d_s, offs, nframes, rows, cols, applied, d_out.data_ptr())
+        td = sess.last_timings() if timing else []
+        assert (dst == 0).all()
+        return offs, te + td
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        offs, _ = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    assert torch.equal(d_out, d_px), "wavelet round trip differs"
+    kmean = mean_timings([step(2)[1] for _ in range(2)])
+    sess.close()
+    raw, comp = d_px.numel() * 2, int(offs[-1]) + 11 * nframes
+    return {"workload": f"WaveletV2 (5 levels) encode+decode, {nframes} CR-like {cols}x{rows} 12-bit synthetic frames per launch, device-resident",
+            "value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "ratio": round(raw / comp, 4), "raw_bytes": raw,
+            "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02}, "roofline": roofline_block(kmean, raw, comp)}
+
+
+def leg_mic2(mic, torch, synth, dev, steps, warmup):
+    """BASELINE config 4: CompressMultiFrame independent mode, 512 frames of 512 x 512 (multiframecompress.go:179-261)"""
+    stack = synth.ct_stack(512, 512, 12, seed=3)
+    d_px = torch.from_numpy(stack.view(np.int16)).to(dev)
+    units = [(i * 512 * 512, 512, 512, 4095, 2) for i in range(512)]
+    res, _, offs = unit_codec_leg(mic, torch, d_px, units, steps, warmup, "MIC2")
+    # container assembly (WriteMIC2, multiframe.go:49-91): 20-byte header + 8 bytes per frame in front of the packed streams
+    t0 = time.perf_counter()
+    hdr = bytearray(20 + 8 * 512)
+    hdr[0:4] = b"MIC2"; hdr[4:8] = (512).to_bytes(4, "little"); hdr[8:12] = (512).to_bytes(4, "little"); hdr[12:16] = (512).to_bytes(4, "little"); hdr[16] = 1
+    for i in range(512):
+        hdr[20 + 8 * i: 24 + 8 * i] = int(offs[i]).to_bytes(4, "little"); hdr[24 + 8 * i: 28 + 8 * i] = int(offs[i + 1] - offs[i]).to_bytes(4, "little")
+    res["container_assembly_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    res["workload"] = "MIC2 independent mode encode+decode, synthetic CT-like stack 512 x 512 x 512 (12-bit), frames as units, device-resident"
+    return res
+
+
+def leg_wsi(mic, torch, synth, dev, steps, size=32768):
+    """BASELINE config 5: CompressWSI, 8-bit RGB, 256 x 256 tiles, full pyramid (wsicompress.go:27-171); decode = every tile of every level"""
+    slide = synth.wsi_slide(size, size, seed=4, workers=min(16, os.cpu_count() or 8))
+    d_px = torch.from_numpy(slide).to(dev)
+    del slide
+    sess = mic.Session(1, 256 * 256)
+    outs = None
+
+    def step(timing=0):
+        nonlocal outs
+        sess.set_timing(timing)
+        t0 = time.perf_counter()
+        tiles, nbytes = sess.wsi_encode(d_px.data_ptr(), size, size)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        te = sess.last_timings() if timing else []
+        lv = sess.wsi_levels()
+        if outs is None:
+            outs = [torch.empty((h, w, 3), dtype=torch.uint8, device=dev) for (w, h) in lv]
+        sess.set_timing(timing)
+        t2 = time.perf_counter()
+        for k in range(len(lv)):
+            sess.wsi_decode_level(k, outs[k].data_ptr(), outs[k].numel())
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        td = sess.last_timings() if timing else []
+        return tiles, nbytes, lv, t1 - t0, t3 - t2, te + td
+
+    step()
+    enc_t, dec_t = [], []
+    for _ in range(steps):
+        tiles, nbytes, lv, a, b, _ = step()
+        enc_t.append(a); dec_t.append(b)
+    assert torch.equal(outs[0], d_px), "WSI level-0 round trip differs"
+    kmean = mean_timings([step(2)[5]])
+    t0 = time.perf_counter()
+    blob = sess.wsi_write()
+    t_write = time.perf_counter() - t0
+    assert len(blob) == nbytes
+    sess.close()
+    raw_l0 = size * size * 3
+    tile_rgb_bytes = sum(((w + 255) // 256) * ((h + 255) // 256) for w, h in lv) * 256 * 256 * 3       # RGB bytes of every tile incl. padding, all levels
+    el = float(np.mean(enc_t) + np.mean(dec_t))
+    # SURVEY.md §8d: 3 N (1 + 1/r) with N = tile pixels including padding (all levels), r = that / compressed bytes
+    return {"workload": f"MIC3 encode (pyramid + tiles + planes) and decode (every tile of every level), synthetic H&E-like {size}x{size} RGB slide, "
+                        f"256x256 tiles, {len(lv)} levels, {tiles} tiles, device-resident",
+            "value": round(raw_l0 / el / 1e9, 4), "unit": "GB/s (level-0 RGB bytes / encode+decode time)", "ms_per_step": round(el * 1e3, 3),
+            "encode_ms": round(float(np.mean(enc_t)) * 1e3, 3), "decode_ms": round(float(np.mean(dec_t)) * 1e3, 3),
+            "ratio": round(raw_l0 / nbytes, 4), "raw_bytes": raw_l0, "compressed_bytes": nbytes,
+            "container_assembly_ms": round(t_write * 1e3, 3),
+            "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.05},
+            "roofline": roofline_block(kmean, tile_rgb_bytes, nbytes)}
 
 
 def main():
@@ -112,13 +284,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "256")),
-                    help="frames per GPU per step (256 x 8 strips = 8 tANS decode streams, 4 two-stream waves, on each of the 256 CUs)")
+    ap.add_argument("--images", type=int, default=int(os.environ.get("MIC_BENCH_IMAGES", "288")),
+                    help="frames per GPU per step (288 x 8 strips = 9 tANS decode streams on each of the 256 CUs)")
     ap.add_argument("--strips", type=int, default=8)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--cols", type=int, default=2577)
     ap.add_argument("--rows", type=int, default=2048)
+    ap.add_argument("--noise", type=float, default=None, help="xr_like noise (default: the level that codes at the published XR ratio 1.755)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip configs 3-5 and the batch sweep")
+    ap.add_argument("--legs-only", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -136,26 +311,22 @@ def main():
 
     mic = entry.load_package()
     synth = importlib.import_module("medical_image_codec_amd.synth")
+    par = importlib.import_module("medical_image_codec_amd.parallel")
     rc = mic.lib().mic_hip_set_device(local)
     if rc:
         raise SystemExit(f"mic_hip_set_device({local}) rc={rc}: libmic_hip.so needs a gfx950 device (no CPU fallback)")
 
     W, H, B, S = args.cols, args.rows, args.images, args.strips
     maxv = (1 << args.depth) - 1
-    # a few distinct frames, tiled over the batch (seed differs per rank)
-    distinct = min(B, 4)
-    base = [synth.xr_like(cols=W, rows=H, depth=args.depth, seed=1 + rank * 16 + i) for i in range(distinct)]
-    host = np.stack([base[i % distinct] for i in range(B)])
-    d_px = torch.from_numpy(host.view(np.int16)).to(dev)
+    noise = args.noise if args.noise is not None else synth.XR_NOISE_PUBLISHED_RATIO
+    seed0 = 1 + rank * 100003
+    d_px = synth.xr_like_batch_torch(B, cols=W, rows=H, depth=args.depth, seed0=seed0, noise=noise, device=dev)   # B distinct frames
     d_out = torch.empty_like(d_px)
     bounds = pics_strips(W, H, S)
-    units = []
-    for b in range(B):
-        for (y0, y1) in bounds:
-            units.append((b * W * H + y0 * W, W, y1 - y0, maxv, 2))
+    units = [(b * W * H + y0 * W, W, y1 - y0, maxv, 2) for b in range(B) for (y0, y1) in bounds]
     n_units = len(units)
     max_px = max(u[1] * u[2] for u in units)
-    sess = mic.Session(n_units, max_px)
+    sess = mic.Session(n_units, max_px, device=local)
     cunits = mic.Session.make_units(units)
 
     def barrier():
@@ -167,92 +338,126 @@ def main():
     def step(timing=False):
         sess.set_timing(timing)
         sess.encode_enqueue(d_px.data_ptr(), cunits)
-        t_enc_k = sess.last_timings() if timing else None
+        t_enc_k = sess.last_timings() if timing else []
         d_blobs, offs, st, ns = sess.encode_finish()
         assert (st == 0).all(), f"encode status {st[st != 0][:4]}"
         sess.decode_enqueue(d_blobs, offs, cunits, d_out.data_ptr())
-        t_dec_k = sess.last_timings() if timing else None
+        t_dec_k = sess.last_timings() if timing else []
         dst = sess.decode_finish()
         assert (dst == 0).all(), f"decode status {dst[dst != 0][:4]}"
-        return offs, t_enc_k, t_dec_k
+        return d_blobs, offs, t_enc_k + t_dec_k
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        offs, _, _ = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    out = {}
+    if not args.legs_only:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d_blobs, offs, _ = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
 
-    # lossless check of the last step (outside the timed region)
-    assert torch.equal(d_out, d_px), "round trip differs"
-    comp_bytes = int(offs[-1])
-    raw_bytes = host.nbytes
-    ratio = raw_bytes / comp_bytes
+        assert torch.equal(d_out, d_px), "round trip differs"             # lossless check of the last step (outside the timed region)
+        comp_bytes = int(offs[-1])
+        raw_bytes = d_px.numel() * 2
+        kmean = mean_timings([step(True)[2] for _ in range(3)])           # per-kernel device times, separate instrumented steps
+        dom = max(kmean, key=kmean.get)
+        traffic = None                                                    # HBM bytes of the dominant kernel from the committed PMC passes (same command)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            ent = tj.get(dom)
+            if ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        ms_step = elapsed / args.steps * 1e3
+        value = raw_bytes * world / (elapsed / args.steps) / 1e9
+        enc_ms = sum(v for k, v in kmean.items() if k.startswith("k_enc") or k.startswith("k_scan"))
+        dec_ms = sum(v for k, v in kmean.items() if k.startswith("k_dec"))
 
-    # per-kernel device times (HIP events on the session stream), separate instrumented steps
-    kt = {}
-    reps = 3
-    for _ in range(reps):
-        _, te, td = step(timing=True)
-        for name, ms in (te + td):
-            kt.setdefault(name, []).append(ms)
-    kmean = {k: float(np.mean(v)) for k, v in kt.items()}
-    dom = max(kmean, key=kmean.get)
-    alg_bytes = raw_bytes + comp_bytes            # one direction: read raw + write compressed (or the reverse)
-    achieved = alg_bytes / (kmean[dom] * 1e-3) / 1e9
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (profiles/, same command); only
-    # quoted when the profile was taken on this very configuration
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        ent = tj.get(dom)
-        if ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
-            traffic = ent["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+        # N > 1: rank 0's view of every rank's streams (what a PICS-per-frame / MIC2 writer on rank 0 needs): sizes all-gather and
+        # a device-to-device gather of the packed blobs over RCCL, timed apart from the step
+        assembly = None
+        if dist is not None:
+            mine = torch.empty(comp_bytes, dtype=torch.uint8, device=dev)
+            mic.device_copy(mine.data_ptr(), d_blobs, comp_bytes)
+            sizes = torch.from_numpy(np.diff(offs.astype(np.int64))).to(dev)
+            barrier()
+            t0 = time.perf_counter()
+            allb, alloffs = par.gather_unit_blobs(mine, sizes, n_units * world, dst=0)
+            barrier()
+            assembly = {"ms": round((time.perf_counter() - t0) * 1e3, 3),
+                        "bytes_on_rank0": int(alloffs[-1]) if rank == 0 else None,
+                        "what": "all_gather of per-unit sizes + send/recv of the packed device blobs to rank 0 (RCCL over xGMI)"}
 
-    ms_step = elapsed / args.steps * 1e3
-    value = raw_bytes * world / (elapsed / args.steps) / 1e9
-    enc_ms = sum(v for k, v in kmean.items() if k.startswith("k_enc") or k.startswith("k_scan"))
-    dec_ms = sum(v for k, v in kmean.items() if k.startswith("k_dec"))
+        out = {
+            "metric": "PICS-8 encode+decode throughput over raw u16 bytes (XR-shaped frames), lossless",
+            "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"PICS-{S} encode+decode, {B} distinct XR-like {W}x{H} {args.depth}-bit synthetic frames ({n_units} strips) per GPU per step, "
+                                   f"noise tuned to the published XR PICS-8 ratio",
+                       "frames_per_gpu": B, "strips_per_frame": S, "width": W, "height": H, "max_value": maxv, "noise": noise,
+                       "fse": "2-state (CompressParallelStrips default)", "parallelism": f"{world} x independent batches"},
+            "ratio": round(raw_bytes / comp_bytes, 4),
+            "encode_GBps_kernels": round(raw_bytes / (enc_ms * 1e-3) / 1e9, 4) if enc_ms else None,
+            "decode_GBps_kernels": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
+            "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02},
+            "roofline": roofline_block(kmean, raw_bytes, comp_bytes, traffic),
+            "container_assembly": assembly,
+        }
+    sess.close()
 
-    out = {
-        "metric": "PICS-8 encode+decode throughput over raw u16 bytes (XR-shaped frames), lossless",
-        "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u16", "data": "synthetic",
-        "config": {"workload": f"PICS-{S} encode+decode, XR-like {W}x{H} {args.depth}-bit synthetic frames, {B} frames ({n_units} strips) per GPU per step",
-                   "frames_per_gpu": B, "strips_per_frame": S, "width": W, "height": H, "max_value": maxv,
-                   "fse": "2-state (CompressParallelStrips default)", "parallelism": f"{world} x independent batches"},
-        "ratio": round(ratio, 4),
-        "encode_GBps_kernels": round(raw_bytes / (enc_ms * 1e-3) / 1e9, 4) if enc_ms else None,
-        "decode_GBps_kernels": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
-        "kernel_ms": {k: round(v, 4) for k, v in kmean.items()},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kmean[dom], 4)},
-    }
-    if rank == 0 and not args.no_cpu and world == 1:
+    if world == 1 and not args.no_legs:
+        # B in {1, 64, 288, 512}: kernel time of one encode+decode per batch size (report B = 1 honestly)
+        sweep = []
+        for b in (1, 64, 288, 512):
+            if b > B:
+                dsw = synth.xr_like_batch_torch(b, cols=W, rows=H, depth=args.depth, seed0=seed0, noise=noise, device=dev)
+            else:
+                dsw = d_px[:b].contiguous()
+            us = [(i * W * H + y0 * W, W, y1 - y0, maxv, 2) for i in range(b) for (y0, y1) in bounds]
+            r, km, _ = unit_codec_leg(mic, torch, dsw, us, 2, 1, f"sweep B={b}")
+            sweep.append({"frames": b, "strips": len(us), "GBps": r["value"], "ms_per_step": r["ms_per_step"],
+                          "encode_GBps_kernels": r["encode_GBps_kernels"], "decode_GBps_kernels": r["decode_GBps_kernels"]})
+            del dsw
+        out["batch_sweep"] = sweep
+        del d_out
+        torch.cuda.empty_cache()
+        legs = {}
+        legs["config3_wavelet_v2_cr"] = leg_wavelet(mic, torch, synth, dev, 3, 1)
+        torch.cuda.empty_cache()
+        legs["config4_mic2_512cubed"] = leg_mic2(mic, torch, synth, dev, 3, 1)
+        torch.cuda.empty_cache()
+        del d_px
+        torch.cuda.empty_cache()
+        legs["config5_mic3_wsi_32768"] = leg_wsi(mic, torch, synth, dev, 2)
+        out["legs"] = legs
+        if "roofline" in out:
+            out["roofline_fracs"] = {"config2_pics8_xr": out["roofline"]["frac"], **{k: (v["roofline"] or {}).get("frac") for k, v in legs.items()}}
+
+    if rank == 0 and not args.no_cpu and not args.legs_only:
         from oracle import mico
         mico.lib()
         ref = load_reference_codec()
-        port = cpu_baseline(mico, base[0], maxv, S, budget_s=8.0)
+        frame0 = synth.xr_like(cols=W, rows=H, depth=args.depth, seed=seed0, noise=noise)      # == frame 0 of the device batch
+        port = cpu_baseline(mico, frame0, maxv, S, budget_s=8.0)
         if ref is not None:
-            out["cpu_baseline"] = cpu_baseline(mico, base[0], maxv, S, budget_s=10.0, ref=ref)
+            out["cpu_baseline"] = cpu_baseline(mico, frame0, maxv, S, budget_s=10.0, ref=ref)
             out["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "encode_GBps", "decode_GBps", "cores")}
         else:
             out["cpu_baseline"] = port
     elif rank == 0:
         out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(out))
-    sess.close()
     if dist is not None:
         dist.destroy_process_group()
 

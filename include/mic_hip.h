@@ -286,6 +286,9 @@ int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs,
  * stream (returned by mic_hip_session_stream as a hipStream_t) without touching the host;
  * results are fetched with the *_finish calls. */
 void *mic_hip_session_stream(mic_hip_session *s);
+/* The buffers a session hands out (*d_blobs, *d_streams) are reused by its next call; a caller that keeps them copies them out:
+ * a device-to-device copy on the calling thread's current device, complete on return. */
+int mic_hip_device_copy(void *d_dst, const void *d_src, size_t bytes);
 int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels,
                                    const mic_hip_unit *units, int n);
 int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs,

@@ -96,6 +96,7 @@ ABI_SYMBOLS = [
     "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
     "mic_hip_session_create", "mic_hip_session_create_on", "mic_hip_session_device", "mic_hip_session_destroy", "mic_hip_session_stream",
+    "mic_hip_device_copy",
     "mic_hip_session_wavelet_v2_encode", "mic_hip_session_wavelet_v2_decode",
     "mic_hip_session_wsi_encode", "mic_hip_session_wsi_write", "mic_hip_session_wsi_decode_level", "mic_hip_session_wsi_levels",
     "mic_hip_session_encode", "mic_hip_session_decode",
@@ -121,6 +122,7 @@ def lib() -> C.CDLL:
     L.mic_hip_session_stream.restype = C.c_void_p
     L.mic_hip_session_stream.argtypes = [C.c_void_p]
     L.mic_hip_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
+    L.mic_hip_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mic_hip_session_create_on.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
     L.mic_hip_session_device.argtypes = [C.c_void_p]
     L.mic_hip_session_wavelet_v2_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
@@ -192,6 +194,13 @@ def lib() -> C.CDLL:
 
 def device_name() -> str:
     return lib().mic_hip_device_name().decode()
+
+
+def device_copy(d_dst: int, d_src: int, nbytes: int) -> None:
+    """device -> device copy (a session's result buffers are reused by its next call)"""
+    rc = lib().mic_hip_device_copy(d_dst, d_src, nbytes)
+    if rc:
+        _raise(rc, "device_copy")
 
 
 def _frame_bound(npx: int) -> int:
@@ -670,13 +679,15 @@ class Session:
     def stream(self) -> int:
         return lib().mic_hip_session_stream(self._h) or 0
 
-    def set_timing(self, on: bool):
-        lib().mic_hip_session_set_timing(self._h, 1 if on else 0)
+    def set_timing(self, on):
+        """False / 0: off; True / 1: per-kernel HIP-event timing of the next launch chain; 2: summed over every launch chain
+        until the next set_timing (calls that run several chains: slabs of a slide, a wavelet pass)."""
+        lib().mic_hip_session_set_timing(self._h, int(on))
 
     def last_timings(self):
-        names = (C.c_char_p * 32)()
-        ms = (C.c_float * 32)()
-        k = lib().mic_hip_session_last_timings(self._h, names, ms, 32)
+        names = (C.c_char_p * 96)()
+        ms = (C.c_float * 96)()
+        k = lib().mic_hip_session_last_timings(self._h, names, ms, 96)
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
     @staticmethod

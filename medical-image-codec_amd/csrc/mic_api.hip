@@ -285,7 +285,15 @@ uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 
 
 extern "C" {
 
-const char *mic_hip_version(void) { return "mic-hip 0.1 (gfx950)"; }
+const char *mic_hip_version(void) { return "mic-hip 0.2 (gfx950)"; }
+
+// device -> device copy on the calling thread's current device, complete on return (a session's result buffers are reused by its
+// next call: a caller that keeps them copies them out)
+int mic_hip_device_copy(void *d_dst, const void *d_src, size_t bytes) {
+    if ((!d_dst || !d_src) && bytes) return MIC_ERR_ARGS;
+    if (bytes) HIP_TRY(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    return MIC_OK;
+}
 
 int mic_hip_set_device(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -755,6 +763,8 @@ int mic_hip_debug_fetch_hist(mic_hip_session *s, int i, void *dst, size_t bytes)
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {
     if (!s) return MIC_ERR_ARGS;
     s->timer.enabled = enabled != 0;
+    s->timer.accumulate = enabled == 2;                                   // 2: sum over every launch chain until the next set_timing
+    s->timer.clear();
     return MIC_OK;
 }
 int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *ms, int cap) {
@@ -763,9 +773,13 @@ int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *
     if (s->timer.used >= 2) {
         if (hipEventSynchronize(s->timer.pool[s->timer.used - 1]) != hipSuccess) return 0;
         for (size_t i = 0; i + 1 < s->timer.used; i++) {
+            if (strcmp(s->timer.names[i], "end") == 0) continue;           // the gap between two launch chains
             float v = 0.f;
             if (hipEventElapsedTime(&v, s->timer.pool[i], s->timer.pool[i + 1]) != hipSuccess) v = -1.f;
-            s->t_names.push_back(s->timer.names[i]); s->t_ms.push_back(v);
+            size_t k = 0;
+            while (k < s->t_names.size() && s->t_names[k] != s->timer.names[i]) k++;
+            if (k == s->t_names.size()) { s->t_names.push_back(s->timer.names[i]); s->t_ms.push_back(v); }
+            else s->t_ms[k] += v;
         }
     }
     int n = (int)std::min<size_t>(s->t_names.size(), (size_t)std::max(cap, 0));

@@ -701,6 +701,7 @@ int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_im
         std::vector<uint32_t> st(nt * P * 2);
         for (size_t k = 0; k < nt * P; k++) { st[2 * k] = 0xFFFFFFFFu; st[2 * k + 1] = 0; }
         HIP_TRY(hipMemcpyAsync(stats.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, s->stream));
+        s->timer.reset(s->stream); s->timer.mark("k_wsi_tile_planes");
         if (P == 3)
             hipLaunchKernelGGL(k_wsi_tile_planes, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img, L.w, L.h,
                                fmt.tw, fmt.th, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
@@ -710,6 +711,7 @@ int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_im
         else
             hipLaunchKernelGGL(k_wsi_tile_plane_grey<uint8_t>, dim3(8, (unsigned)nt), dim3(256), 0, s->stream, (const uint8_t *)d_img,
                                L.w, L.h, fmt.tw, fmt.th, L.tx, (int)t0, (uint16_t *)planes.p, (uint32_t *)stats.p);
+        s->timer.mark("end");
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(st.data(), stats.p, st.size() * 4, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -778,8 +780,9 @@ int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int 
     std::vector<DevBuf> &img = s->wsi_pyr;
     if (img.size() < W.lv.size()) img.resize(W.lv.size());
     const void *prev = d_pixels;
+    for (size_t i = 1; i < W.lv.size(); i++) if ((rc = img[i].reserve((size_t)W.lv[i].w * W.lv[i].h * bpp + 64))) return rc;
+    s->timer.reset(s->stream); s->timer.mark("k_wsi_downsample");
     for (size_t i = 1; i < W.lv.size(); i++) {
-        if ((rc = img[i].reserve((size_t)W.lv[i].w * W.lv[i].h * bpp + 64))) return rc;
         if (channels == 3)
             hipLaunchKernelGGL(k_wsi_downsample, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)prev, W.lv[i - 1].w, (uint8_t *)img[i].p, W.lv[i].w, W.lv[i].h);
         else if (bits_per_sample == 16)
@@ -788,6 +791,7 @@ int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int 
             hipLaunchKernelGGL(k_wsi_downsample_grey<uint8_t>, dim3(1024), dim3(256), 0, s->stream, (const uint8_t *)prev, W.lv[i - 1].w, (uint8_t *)img[i].p, W.lv[i].w, W.lv[i].h);
         prev = img[i].p;
     }
+    s->timer.mark("end");
     HIP_TRY(hipGetLastError());
     for (size_t i = 0; i < W.lv.size(); i++)
         if ((rc = store_level_tiles(s, W, i == 0 ? (const void *)d_pixels : (const void *)img[i].p, W.lv[i]))) return rc;
@@ -889,6 +893,7 @@ int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_p
         HIP_TRY(hipMemcpyAsync(d_place, place.data(), nt * sizeof(int4), hipMemcpyHostToDevice, s->stream));
         if (!fills.empty()) {
             HIP_TRY(hipMemcpyAsync(d_fill, fills.data(), fills.size() * sizeof(uint2), hipMemcpyHostToDevice, s->stream));
+            s->timer.reset(s->stream); s->timer.mark("k_fill_planes");
             for (size_t f0 = 0; f0 < fills.size(); f0 += 65535)
                 hipLaunchKernelGGL(k_fill_planes, dim3(4, (unsigned)std::min<size_t>(65535, fills.size() - f0)), dim3(256), 0, s->stream, dp, npx, (const uint2 *)d_fill + f0);
         }
@@ -898,12 +903,14 @@ int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_p
             if ((rc = session_decode_finish(s, st.data()))) return rc;
             for (int32_t v : st) if (v != MIC_OK) return v;
         }
+        s->timer.reset(s->stream); s->timer.mark("k_wsi_planes_to_pixels");
         if (P == 3)
             hipLaunchKernelGGL(k_wsi_planes_to_rgb, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, d_pixels_out, L.w);
         else if (m.bps == 16)
             hipLaunchKernelGGL(k_wsi_plane_to_grey<uint16_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, (uint16_t *)d_pixels_out, L.w);
         else
             hipLaunchKernelGGL(k_wsi_plane_to_grey<uint8_t>, dim3(16, (unsigned)nt), dim3(256), 0, s->stream, dp, m.tw, m.th, (const int4 *)d_place, d_pixels_out, L.w);
+        s->timer.mark("end");
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s->stream));
     }

@@ -25,11 +25,13 @@ struct MicPerDeviceOnce {
 // consecutive events into per-kernel device milliseconds.
 struct MicTimer {
     bool enabled = false;
+    bool accumulate = false;           // keep the marks of earlier enqueues (a call that runs several launch chains, e.g. slabs)
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> pool;
     std::vector<const char *> names;   // names[i] labels the span ev[i] .. ev[i+1]
     size_t used = 0;
-    void reset(hipStream_t s) { stream = s; used = 0; names.clear(); }
+    void reset(hipStream_t s) { stream = s; if (!accumulate) { used = 0; names.clear(); } }
+    void clear() { used = 0; names.clear(); }
     void mark(const char *name) {
         if (!enabled) return;
         if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pool.push_back(e); }

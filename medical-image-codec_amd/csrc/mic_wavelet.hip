@@ -325,6 +325,8 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
     auto done = [&](int code) { return code; };
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
+    s->timer.reset(s->stream);
+    s->timer.mark("k_wv_load+fwd_rows+fwd_cols");
     hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
     { int r = rows, c = cols;
       for (int l = 0; l < applied; l++) {
@@ -340,8 +342,9 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     }
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     if (hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    s->timer.mark("k_wv_symbols");
     hipLaunchKernelGGL(k_wv_symbols, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, wv_dims(rows, cols, applied));
-    mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr);
+    mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer);
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
     s->n_last = nf;
     std::vector<uint64_t> offs((size_t)nf + 1); std::vector<int32_t> ns((size_t)nf); const uint8_t *d_blobs = nullptr;
@@ -377,16 +380,22 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
     if (hipMemsetAsync(A, 0, n * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, nullptr, (int *)s->cls.p);
+    s->timer.reset(s->stream);
+    mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer, (int *)s->cls.p);
     const WvDims d = wv_dims(rows, cols, levels);
+    if (s->timer.used) { s->timer.used--; s->timer.names.pop_back(); }   // (drop the chain's "end" mark: the wavelet kernels follow)
+    s->timer.mark("k_wv_expand");
     hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
+    s->timer.mark("k_wv_coeffs");
     hipLaunchKernelGGL(k_wv_coeffs, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
+    s->timer.mark("k_wv_inv_cols+inv_rows+store");
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];
         hipLaunchKernelGGL(k_wv_inv_cols, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n);
         hipLaunchKernelGGL(k_wv_inv_rows, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, cc, cols, n);
     }
     hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
+    s->timer.mark("end");
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
     s->n_last = nf;
     st.assign((size_t)nf, 0);

@@ -1,9 +1,13 @@
 """Static sharding of independent units over the GPUs of one node.
 
-Strips, MIC2 frames and MIC3 tiles share no data, so the only cross-rank traffic is the assembly of
-a container: an all-gather of per-unit compressed sizes (8 B per unit) and a gather of the blobs to
-rank 0.  No all-reduce, no data-path collective inside the codec.  The codec is injected, so the
-CPU tests can drive the plumbing with gloo and a stand-in codec.
+Strips (parallelstrips.go:77-93), MIC2 frames (multiframecompress.go:201-203) and MIC3 tiles (wsicompress.go:83-145) share no data,
+so a rank codes a contiguous range of the units and the only cross-rank traffic is the assembly of a container on one rank:
+an all-gather of the per-unit compressed sizes (8 bytes per unit) and a gather of the packed blobs -- point-to-point sends into
+the slices of ONE buffer on the destination rank, exact sizes, no padding.  On the `nccl` backend (= RCCL) every tensor here is a
+device tensor, so the blobs go GPU to GPU over xGMI and never touch the host; on `gloo` (the CPU tests) the same code moves CPU
+tensors.  Decode is the mirror image: the owner of a container scatters each rank's slice, every rank decodes its units.
+No all-reduce, no collective inside the codec.  The codec is injected (a callable), so the CPU tests drive the plumbing with
+gloo and the oracle, and the GPU tests / bench.py with a mic_hip session.
 """
 from __future__ import annotations
 
@@ -13,61 +17,235 @@ import numpy as np
 
 
 def shard_range(n_units: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous static partition: unit i belongs to rank i*world//n_units (each rank's output is one
-    contiguous blob range)."""
+    """Contiguous static partition: rank r owns units [n*r/world, n*(r+1)/world) (each rank's output is one
+    contiguous blob range of the container)."""
     lo = (n_units * rank) // world
     hi = (n_units * (rank + 1)) // world
     return lo, hi
 
 
-def write_mic2(width: int, height: int, blobs: Sequence[bytes]) -> bytes:
-    """WriteMIC2 (multiframe.go:49-91), independent mode."""
-    n = len(blobs)
+def _dist(group):
+    import torch.distributed as dist
+    return dist, dist.get_world_size(group), dist.get_rank(group)
+
+
+def gather_unit_blobs(local_blobs, local_sizes, n_units_total: int, dst: int = 0, group=None):
+    """local_blobs: uint8 tensor, this rank's units back to back; local_sizes: int64 tensor, one size per local unit (both on
+    the backend's device).  Returns (all blobs in global unit order as ONE uint8 tensor on `dst`, None elsewhere;
+    offsets[n_units_total + 1] as a numpy int64 array on every rank)."""
+    import torch
+    dist, world, rank = _dist(group)
+    lo, hi = shard_range(n_units_total, world, rank)
+    assert local_sizes.numel() == hi - lo, (local_sizes.numel(), lo, hi)
+    dev = local_blobs.device
+    per = max(shard_range(n_units_total, world, r)[1] - shard_range(n_units_total, world, r)[0] for r in range(world))
+    mine = torch.zeros(max(per, 1), dtype=torch.int64, device=dev)
+    mine[: hi - lo] = local_sizes.to(torch.int64)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)                                      # 1. sizes: 8 bytes per unit
+    sizes = np.concatenate([parts[r][: shard_range(n_units_total, world, r)[1] - shard_range(n_units_total, world, r)[0]].cpu().numpy()
+                            for r in range(world)]).astype(np.int64)
+    offs = np.zeros(n_units_total + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offs[1:])
+    shard_bytes = [int(offs[shard_range(n_units_total, world, r)[1]] - offs[shard_range(n_units_total, world, r)[0]]) for r in range(world)]
+    assert local_blobs.numel() >= shard_bytes[rank]
+    out = None
+    if rank == dst:                                                                # 2. payloads: straight into their place
+        out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
+        reqs = []
+        for r in range(world):
+            b0 = int(offs[shard_range(n_units_total, world, r)[0]])
+            if r == rank:
+                out[b0: b0 + shard_bytes[r]] = local_blobs[: shard_bytes[r]]
+            elif shard_bytes[r]:
+                reqs.append(dist.irecv(out[b0: b0 + shard_bytes[r]], src=_global_rank(dist, group, r), group=group))
+        for q in reqs:
+            q.wait()
+    elif shard_bytes[rank]:
+        dist.send(local_blobs[: shard_bytes[rank]].contiguous(), dst=_global_rank(dist, group, dst), group=group)
+    return out, offs
+
+
+def scatter_unit_blobs(all_blobs, offs: np.ndarray, n_units_total: int, src: int = 0, group=None, device=None):
+    """The mirror image: `src` holds all blobs (global unit order) and the offsets; every rank receives the slice of its
+    units.  Returns (local blobs tensor, local offsets rebased to 0)."""
+    import torch
+    dist, world, rank = _dist(group)
+    meta = torch.zeros(n_units_total + 1, dtype=torch.int64, device=device if device is not None else (all_blobs.device if all_blobs is not None else "cpu"))
+    if rank == src:
+        meta.copy_(torch.from_numpy(np.asarray(offs, dtype=np.int64)))
+    dist.broadcast(meta, src=_global_rank(dist, group, src), group=group)          # the offset table: 8 bytes per unit
+    o = meta.cpu().numpy()
+    lo, hi = shard_range(n_units_total, world, rank)
+    nbytes = int(o[hi] - o[lo])
+    local = torch.empty(nbytes, dtype=torch.uint8, device=meta.device)
+    if rank == src:
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_units_total, world, r)
+            piece = all_blobs[int(o[rlo]): int(o[rhi])]
+            if r == rank:
+                local.copy_(piece)
+            elif piece.numel():
+                reqs.append(dist.isend(piece.contiguous(), dst=_global_rank(dist, group, r), group=group))
+        for q in reqs:
+            q.wait()
+    elif nbytes:
+        dist.recv(local, src=_global_rank(dist, group, src), group=group)
+    return local, (o[lo: hi + 1] - o[lo]).astype(np.int64)
+
+
+def _global_rank(dist, group, r: int) -> int:
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+# ---- containers around gathered units ------------------------------------------------------------------------------------------
+def mic2_header(width: int, height: int, sizes: Sequence[int]) -> bytes:
+    """WriteMIC2 (multiframe.go:49-91), independent mode: 20-byte header + (offset, length) u32 per frame."""
+    n = len(sizes)
     hdr = bytearray(20 + 8 * n)
     hdr[0:4] = b"MIC2"
     hdr[4:8] = int(width).to_bytes(4, "little"); hdr[8:12] = int(height).to_bytes(4, "little")
     hdr[12:16] = n.to_bytes(4, "little"); hdr[16] = 0x01
     off = 0
-    for i, b in enumerate(blobs):
+    for i, ln in enumerate(sizes):
         hdr[20 + 8 * i: 24 + 8 * i] = off.to_bytes(4, "little")
-        hdr[24 + 8 * i: 28 + 8 * i] = len(b).to_bytes(4, "little")
-        off += len(b)
-    return bytes(hdr) + b"".join(blobs)
+        hdr[24 + 8 * i: 28 + 8 * i] = int(ln).to_bytes(4, "little")
+        off += int(ln)
+    return bytes(hdr)
 
 
-def dist_compress_multi_frame(frames_local: Sequence[np.ndarray], width: int, height: int, max_value: int,
-                              n_frames_total: int, codec: Callable[[np.ndarray, int, int, int], bytes],
-                              group=None) -> Optional[bytes]:
-    """Each rank compresses its contiguous shard of an n_frames_total stack (frames_local = the frames of
-    shard_range(n_frames_total, world, rank)); rank 0 returns the MIC2 file, the others None."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+def write_mic2(width: int, height: int, blobs: Sequence[bytes]) -> bytes:
+    return mic2_header(width, height, [len(b) for b in blobs]) + b"".join(blobs)
+
+
+def pics_header(width: int, height: int, strip_h: int, sizes: Sequence[int]) -> bytes:
+    """PICS (parallelstrips.go:20-28, :101-123): magic, width, height, strips, strip height, (offset, length) u32 per strip."""
+    n = len(sizes)
+    hdr = bytearray(20 + 8 * n)
+    hdr[0:4] = b"PICS"
+    for k, v in enumerate((width, height, n, strip_h)):
+        hdr[4 + 4 * k: 8 + 4 * k] = int(v).to_bytes(4, "little")
+    off = 0
+    for i, ln in enumerate(sizes):
+        hdr[20 + 8 * i: 24 + 8 * i] = off.to_bytes(4, "little")
+        hdr[24 + 8 * i: 28 + 8 * i] = int(ln).to_bytes(4, "little")
+        off += int(ln)
+    return bytes(hdr)
+
+
+# EncodeUnits: (first unit, one past the last unit) of the GLOBAL unit list -> (uint8 tensor of the blobs back to back,
+# int64 tensor of their sizes), both on the backend's device.  DecodeUnits: (lo, hi, blobs tensor, offsets) -> pixels of the units.
+EncodeUnits = Callable[[int, int], Tuple["object", "object"]]
+
+
+def dist_compress_multi_frame(encode_units: EncodeUnits, width: int, height: int, n_frames_total: int, group=None) -> Optional[bytes]:
+    """CompressMultiFrame (independent mode, multiframecompress.go:179-261) over the ranks: frame i is coded by the rank that
+    owns it, rank 0 returns the MIC2 file (the others None)."""
+    dist, world, rank = _dist(group)
     lo, hi = shard_range(n_frames_total, world, rank)
-    assert len(frames_local) == hi - lo
-    blobs = [codec(f, width, height, max_value) for f in frames_local]
-    # 1. all-gather of the per-frame sizes (fixed-length vector, zero padded)
-    per = (n_frames_total + world - 1) // world + 1
-    mine = torch.zeros(per, dtype=torch.int64)
-    mine[: len(blobs)] = torch.tensor([len(b) for b in blobs], dtype=torch.int64)
-    sizes = [torch.zeros(per, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
-    # 2. gather of the payloads to rank 0 (byte tensors, padded to the largest shard)
-    payload = np.frombuffer(b"".join(blobs), dtype=np.uint8)
-    totals = [int(s.sum()) for s in sizes]
-    cap = max(max(totals), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8)
-    buf[: payload.size] = torch.from_numpy(payload.copy())
-    gathered = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0, group=group)
+    blobs, sizes = encode_units(lo, hi)
+    allb, offs = gather_unit_blobs(blobs, sizes, n_frames_total, dst=0, group=group)
     if rank != 0:
         return None
-    out: List[bytes] = []
-    for r in range(world):
-        rlo, rhi = shard_range(n_frames_total, world, r)
-        data = gathered[r].numpy().tobytes()
-        off = 0
-        for k in range(rhi - rlo):
-            ln = int(sizes[r][k])
-            out.append(data[off: off + ln]); off += ln
-    return write_mic2(width, height, out)
+    return mic2_header(width, height, np.diff(offs)) + allb.cpu().numpy().tobytes()
+
+
+def dist_decompress_multi_frame(decode_units, mic2: Optional[bytes], group=None, device=None):
+    """DecompressMultiFrame over the ranks: rank 0 holds the file, every rank receives the streams of its frames and decodes
+    them; returns (lo, hi, what decode_units returned for frames [lo, hi))."""
+    import torch
+    dist, world, rank = _dist(group)
+    dev = device if device is not None else "cpu"
+    head = torch.zeros(3, dtype=torch.int64, device=dev)
+    allb, offs = None, None
+    if rank == 0:
+        w = int.from_bytes(mic2[4:8], "little"); h = int.from_bytes(mic2[8:12], "little"); n = int.from_bytes(mic2[12:16], "little")
+        head.copy_(torch.tensor([w, h, n], dtype=torch.int64))
+        tab = np.frombuffer(mic2, dtype="<u4", count=2 * n, offset=20).reshape(n, 2)
+        offs = np.concatenate([tab[:, 0].astype(np.int64), [int(tab[-1, 0]) + int(tab[-1, 1])]])
+        allb = torch.from_numpy(np.frombuffer(mic2, dtype=np.uint8, offset=20 + 8 * n).copy()).to(dev)
+    dist.broadcast(head, src=_global_rank(dist, group, 0), group=group)
+    w, h, n = (int(v) for v in head.cpu())
+    local, loffs = scatter_unit_blobs(allb, offs, n, src=0, group=group, device=dev)
+    lo, hi = shard_range(n, world, rank)
+    return lo, hi, decode_units(lo, hi, local, loffs, w, h)
+
+
+def dist_compress_pics_batch(encode_units: EncodeUnits, width: int, height: int, num_strips: int, n_frames_total: int, group=None) -> Optional[List[bytes]]:
+    """A batch of frames, each a PICS file of num_strips strips (CompressParallelStrips, parallelstrips.go:55-124): frames are
+    sharded over the ranks (units = strips, frame-major), rank 0 returns the PICS files."""
+    dist, world, rank = _dist(group)
+    ns = max(1, min(num_strips, height)); sh = (height + ns - 1) // ns; actual = (height + sh - 1) // sh
+    flo, fhi = shard_range(n_frames_total, world, rank)
+    blobs, sizes = encode_units(flo * actual, fhi * actual)
+    # the unit partition must be the frame partition: gather per frame-shard
+    allb, offs = _gather_by_shards(blobs, sizes, [(shard_range(n_frames_total, world, r)[0] * actual, shard_range(n_frames_total, world, r)[1] * actual)
+                                                  for r in range(world)], group)
+    if rank != 0:
+        return None
+    host = allb.cpu().numpy()
+    files = []
+    for f in range(n_frames_total):
+        o = offs[f * actual: (f + 1) * actual + 1]
+        files.append(pics_header(width, height, sh, np.diff(o)) + host[int(o[0]): int(o[-1])].tobytes())
+    return files
+
+
+def _gather_by_shards(blobs, sizes, ranges: Sequence[Tuple[int, int]], group):
+    """gather_unit_blobs for an explicit (contiguous, ordered) unit range per rank"""
+    import torch
+    dist, world, rank = _dist(group)
+    total = ranges[-1][1]
+    dev = blobs.device
+    per = max(1, max(hi - lo for lo, hi in ranges))
+    mine = torch.zeros(per, dtype=torch.int64, device=dev)
+    mine[: sizes.numel()] = sizes.to(torch.int64)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    allsz = np.concatenate([parts[r][: ranges[r][1] - ranges[r][0]].cpu().numpy() for r in range(world)]).astype(np.int64)
+    offs = np.zeros(total + 1, dtype=np.int64)
+    np.cumsum(allsz, out=offs[1:])
+    nb = [int(offs[hi] - offs[lo]) for lo, hi in ranges]
+    out = None
+    if rank == 0:
+        out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
+        reqs = []
+        for r, (lo, hi) in enumerate(ranges):
+            if r == 0:
+                out[: nb[0]] = blobs[: nb[0]]
+            elif nb[r]:
+                reqs.append(dist.irecv(out[int(offs[lo]): int(offs[lo]) + nb[r]], src=_global_rank(dist, group, r), group=group))
+        for q in reqs:
+            q.wait()
+    elif nb[rank]:
+        dist.send(blobs[: nb[rank]].contiguous(), dst=_global_rank(dist, group, 0), group=group)
+    return out, offs
+
+
+# ---- the injected codec on a GPU: a mic_hip session over a device-resident unit array ---------------------------------------
+def session_codec(mic, sess, d_pixels, units: Sequence[Tuple[int, int, int, int, int]]):
+    """EncodeUnits / DecodeUnits over `units` = the GLOBAL list (px_offset relative to this rank's d_pixels for the units it
+    owns).  Blobs come back as a device tensor copied out of the session (the session reuses its packed buffer)."""
+    import torch
+
+    def encode(lo: int, hi: int):
+        cu = mic.Session.make_units(list(units[lo:hi]))
+        sess.encode_enqueue(d_pixels.data_ptr(), cu)
+        d_blobs, offs, st, _ = sess.encode_finish()
+        if (st != 0).any():
+            raise mic.MicError(int(st[st != 0][0]), "session_codec.encode")
+        out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=d_pixels.device)
+        mic.device_copy(out.data_ptr(), d_blobs, int(offs[-1]))
+        return out, torch.from_numpy(np.diff(offs.astype(np.int64))).to(d_pixels.device)
+
+    def decode(lo: int, hi: int, blobs, offs, w: int, h: int):
+        cu = mic.Session.make_units([(i * w * h, w, h, 0, 0) for i in range(hi - lo)])
+        out = torch.empty((hi - lo, h, w), dtype=torch.int16, device=blobs.device)
+        sess.decode_enqueue(blobs.data_ptr(), offs.astype(np.uint64), cu, out.data_ptr())
+        st = sess.decode_finish()
+        if (st != 0).any():
+            raise mic.MicError(int(st[st != 0][0]), "session_codec.decode")
+        return out
+
+    return encode, decode

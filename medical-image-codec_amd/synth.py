@@ -37,11 +37,8 @@ def approx_gauss(n: int, seed: int) -> np.ndarray:
     return s
 
 
-def xr_like(cols: int = 2577, rows: int = 2048, depth: int = 12, seed: int = 1,
-            noise: float = 18.0) -> np.ndarray:
-    """'XR-like' frame of the reference's XR shape (cols 2577 x rows 2048,
-    fseu16_test.go:32): smooth anatomy-like field + signal-dependent noise, collimator
-    border (constant -> RLE runs) and a few saturated markers (-> escape path)."""
+def _xr_field(cols: int, rows: int, depth: int):
+    """The noise-free part of xr_like: (f * maxv, sqrt(f + 0.1)) as float64 (rows, cols)."""
     maxv = (1 << depth) - 1
     y = np.linspace(-1.0, 1.0, rows, dtype=np.float64)[:, None]
     x = np.linspace(-1.0, 1.0, cols, dtype=np.float64)[None, :]
@@ -50,20 +47,79 @@ def xr_like(cols: int = 2577, rows: int = 2048, depth: int = 12, seed: int = 1,
     f -= 0.22 * np.exp(-((x + 0.35) ** 2 / 0.02 + (y - 0.2) ** 2 / 0.5))
     f += 0.03 * np.sin(23.0 * x) * np.sin(17.0 * y)
     f = np.clip(f, 0.02, 0.98)
-    img = f * maxv
-    g = approx_gauss(rows * cols, seed).reshape(rows, cols)
-    img = img + g * noise * (maxv / 4095.0) * np.sqrt(f + 0.1)
-    img = np.clip(np.rint(img), 0, maxv).astype(np.uint16)
+    return f * maxv, np.sqrt(f + 0.1)
+
+
+def _xr_marks(img, cols: int, rows: int, maxv: int):
+    """collimator border (constant -> RLE runs) and a few saturated markers (-> escape path); img: (..., rows, cols)"""
     b = max(4, rows // 64)
-    img[:b, :] = 0
-    img[-b:, :] = 0
-    img[:, : max(4, cols // 80)] = 0
-    img[:, -max(4, cols // 80):] = 0
-    # lead markers: saturated blobs, sharp edges -> |diff| >= T escapes
-    for k in range(6):
+    img[..., :b, :] = 0
+    img[..., -b:, :] = 0
+    img[..., :, : max(4, cols // 80)] = 0
+    img[..., :, -max(4, cols // 80):] = 0
+    for k in range(6):                                                   # lead markers: saturated blobs, sharp edges -> |diff| >= T escapes
         cy = int(rows * (0.15 + 0.12 * k)); cx = int(cols * (0.1 + 0.14 * k))
-        img[cy:cy + 24, cx:cx + 24] = maxv
+        img[..., cy:cy + 24, cx:cx + 24] = maxv
     return img
+
+
+XR_NOISE_PUBLISHED_RATIO = 167.0   # xr_like noise at which PICS-8 of the 2577 x 2048 frame codes at ~1.755, the reference's published XR ratio
+
+
+def xr_like(cols: int = 2577, rows: int = 2048, depth: int = 12, seed: int = 1,
+            noise: float = 18.0) -> np.ndarray:
+    """'XR-like' frame of the reference's XR shape (cols 2577 x rows 2048,
+    fseu16_test.go:32): smooth anatomy-like field + signal-dependent noise, collimator
+    border (constant -> RLE runs) and a few saturated markers (-> escape path).
+    noise = 18 codes at ratio ~2.65 (PICS-8); XR_NOISE_PUBLISHED_RATIO at the reference's published 1.755."""
+    maxv = (1 << depth) - 1
+    fm, sq = _xr_field(cols, rows, depth)
+    g = approx_gauss(rows * cols, seed).reshape(rows, cols)
+    img = fm + g * noise * (maxv / 4095.0) * sq
+    img = np.clip(np.rint(img), 0, maxv).astype(np.uint16)
+    return _xr_marks(img, cols, rows, maxv)
+
+
+def xr_like_batch_torch(n: int, cols: int = 2577, rows: int = 2048, depth: int = 12, seed0: int = 1, noise: float = 18.0,
+                        device="cuda", chunk: int = 8):
+    """n DISTINCT frames, frame i == xr_like(cols, rows, depth, seed0 + i, noise) bit for bit, made on the device (torch is
+    plumbing here: the same splitmix64 hash in int64 arithmetic, the same float64 operations in the same order -- IEEE add,
+    multiply, divide and round-half-even give the numpy result).  Returns an int16 tensor (n, rows, cols) holding the u16 bits."""
+    import torch
+    maxv = (1 << depth) - 1
+    fm_h, sq_h = _xr_field(cols, rows, depth)
+    fm = torch.from_numpy(fm_h).to(device).reshape(-1)
+    sq = torch.from_numpy(sq_h).to(device).reshape(-1)
+    npx = rows * cols
+    idx = torch.arange(npx, dtype=torch.int64, device=device)
+    out = torch.empty((n, rows, cols), dtype=torch.int16, device=device)
+
+    def s64(v):                                                          # python int -> the int64 with the same 64 bits
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >> 63 else v
+
+    def lsr(z, k):                                                       # logical shift right of int64 bit patterns
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    scale = float(np.sqrt(4.0 / 12.0) * 65536.0)
+    amp = maxv / 4095.0
+    for i0 in range(0, n, chunk):
+        k = min(chunk, n - i0)
+        seeds = torch.arange(seed0 + i0, seed0 + i0 + k, dtype=torch.int64, device=device)[:, None]
+        z = idx[None, :] + (seeds << 32) + s64(0x9E3779B97F4A7C15)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        h = z ^ lsr(z, 31)
+        s = torch.zeros((k, npx), dtype=torch.float64, device=device)
+        for j in range(4):
+            s += ((h >> (16 * j)) & 0xFFFF).to(torch.float64)
+        g = (s - 4 * 32767.5) / scale
+        img = fm[None, :] + g * noise * amp * sq[None, :]
+        img = torch.clamp(torch.round(img), 0, maxv).to(torch.int32).reshape(k, rows, cols)
+        img = _xr_marks(img, cols, rows, maxv)
+        out[i0:i0 + k] = img.to(torch.int16)                             # (wraps above 32767: the u16 bit pattern)
+        del z, h, s, g, img
+    return out
 
 
 def cr_like(cols: int = 1760, rows: int = 2140, depth: int = 12, seed: int = 2) -> np.ndarray:

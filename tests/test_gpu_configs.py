@@ -159,3 +159,44 @@ def test_session_wsi_device_resident(mic, mico, synth, gpu_ready):
         assert np.array_equal(d_out.cpu().numpy(), img), f"level {k}"
         img = _box2(img)
     sess.close()
+
+
+def test_xr_batch_generator_on_the_device_equals_numpy(synth, gpu_ready):
+    """bench.py's frames are made on the device: the same hash and the same float64 operations as synth.xr_like, bit for bit."""
+    pytest.importorskip("torch")
+    d = synth.xr_like_batch_torch(3, cols=2577, rows=2048, depth=12, seed0=7, noise=synth.XR_NOISE_PUBLISHED_RATIO, device="cuda")
+    want = synth.xr_like(cols=2577, rows=2048, depth=12, seed=8, noise=synth.XR_NOISE_PUBLISHED_RATIO)
+    assert np.array_equal(d[1].cpu().numpy().view(np.uint16), want)
+
+
+def test_parallel_gather_on_rccl_world_size_1(mic, mico, synth, gpu_ready):
+    """parallel.py on the backend bench.py uses (`nccl` = RCCL) with the real session codec and device tensors: one rank here (the
+    box has one GPU); the two-rank logic runs under gloo in tests/test_parallel_cpu.py."""
+    torch = pytest.importorskip("torch")
+    import importlib
+    import torch.distributed as dist
+    par = importlib.import_module("medical_image_codec_amd.parallel")
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 2000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        stack = np.stack([synth.xr_like(cols=320, rows=200, depth=12, seed=60 + i) for i in range(6)])
+        d_px = torch.from_numpy(stack.view(np.int16).copy()).cuda()
+        sess = mic.Session(12, 320 * 200, device=0)
+        units = [(i * 320 * 200, 320, 200, 4095, 2) for i in range(6)]
+        enc, dec = par.session_codec(mic, sess, d_px, units)
+        mic2 = par.dist_compress_multi_frame(enc, 320, 200, 6)
+        rc, want = mico.mic2_compress(stack, 4095, False)
+        assert rc == 0 and mic2 == want
+        lo, hi, px = par.dist_decompress_multi_frame(dec, mic2, device=torch.device("cuda:0"))
+        assert (lo, hi) == (0, 6) and torch.equal(px, d_px.reshape(6, 200, 320))
+        sh = 100
+        strips = [(f * 320 * 200 + y0 * 320, 320, sh, 4095, 2) for f in range(6) for y0 in (0, 100)]
+        enc_s, _ = par.session_codec(mic, sess, d_px, strips)
+        pics = par.dist_compress_pics_batch(enc_s, 320, 200, 2, 6)
+        for f in range(6):
+            rc, pw = mico.pics_compress(stack[f], 4095, 2, 2)
+            assert rc == 0 and pics[f] == pw
+        sess.close()
+    finally:
+        dist.destroy_process_group()

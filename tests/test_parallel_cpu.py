@@ -1,6 +1,7 @@
-"""World-size-2 gloo test (CPU) of the multi-GPU plumbing: static frame sharding, size all-gather, blob
-gather, MIC2 assembly.  The codec is a stand-in here (the oracle), exactly as the HIP codec is injected on
-a GPU node; the assembled file must equal the single-process oracle MIC2."""
+"""World-size-2 gloo tests (CPU) of the multi-GPU plumbing: static unit sharding, size all-gather, point-to-point blob gather /
+scatter, MIC2 and PICS assembly, sharded decode.  The codec is a stand-in here (the oracle, on CPU tensors), exactly as the
+mic_hip session is injected on a GPU node (parallel.session_codec; tests/test_gpu_parity.py runs that on one rank with `nccl`);
+the assembled files must equal the single-process oracle's."""
 import os
 import sys
 
@@ -9,6 +10,32 @@ import pytest
 import torch.multiprocessing as mp
 
 from conftest import ROOT, load_package
+
+
+def _oracle_codec(mico, stack, maxv, units=None):
+    """EncodeUnits / DecodeUnits over frames (units = None) or over explicit (frame, y0, y1) strips, on CPU tensors"""
+    import torch
+
+    def encode(lo, hi):
+        blobs = []
+        for i in range(lo, hi):
+            px = stack[i] if units is None else stack[units[i][0], units[i][1]:units[i][2]]
+            rc, blob = mico.compress_single_frame(np.ascontiguousarray(px), maxv, 2)
+            assert rc == 0
+            blobs.append(blob)
+        flat = np.frombuffer(b"".join(blobs), dtype=np.uint8).copy()
+        return torch.from_numpy(flat), torch.tensor([len(b) for b in blobs], dtype=torch.int64)
+
+    def decode(lo, hi, blobs, offs, w, h):
+        host = blobs.numpy().tobytes()
+        out = []
+        for k in range(hi - lo):
+            rc, px = mico.decompress_single_frame(host[int(offs[k]):int(offs[k + 1])], w, h)
+            assert rc == 0
+            out.append(px)
+        return np.stack(out) if out else np.zeros((0, h, w), np.uint16)
+
+    return encode, decode
 
 
 def _worker(rank, world, port, stack, q):
@@ -22,16 +49,17 @@ def _worker(rank, world, port, stack, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n, h, w = stack.shape
-        lo, hi = par.shard_range(n, world, rank)
-
-        def codec(f, width, height, mv):
-            rc, blob = mico.compress_single_frame(f, mv, 2)
-            assert rc == 0
-            return blob
-
-        out = par.dist_compress_multi_frame([stack[i] for i in range(lo, hi)], w, h, 4095, n, codec)
+        enc, dec = _oracle_codec(mico, stack, 4095)
+        mic2 = par.dist_compress_multi_frame(enc, w, h, n)                       # encode: shard, gather sizes + blobs, assemble
+        lo, hi, px = par.dist_decompress_multi_frame(dec, mic2)                   # decode: scatter the streams, decode the shard
+        assert (lo, hi) == par.shard_range(n, world, rank) and np.array_equal(px, stack[lo:hi])
+        ns = 3
+        sh = (h + ns - 1) // ns
+        strips = [(f, y0, min(h, y0 + sh)) for f in range(n) for y0 in range(0, h, sh)]
+        enc_s, _ = _oracle_codec(mico, stack, 4095, strips)
+        pics = par.dist_compress_pics_batch(enc_s, w, h, ns, n)                  # PICS batches: frames sharded, strips as units
         if rank == 0:
-            q.put(out)
+            q.put((mic2, pics))
     finally:
         dist.destroy_process_group()
 
@@ -47,8 +75,8 @@ def test_shard_range_is_a_partition(mic):
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
 
 
-def test_two_rank_mic2_assembly_matches_single_process(mico, synth):
-    stack = synth.ct_stack(frames=5, size=128, depth=12, seed=8)
+def test_two_rank_mic2_and_pics_assembly_match_single_process(mico, synth):
+    stack = np.stack([synth.xr_like(cols=128, rows=128, depth=12, seed=80 + i) for i in range(5)])   # (every strip codes: no constant one)
     rc, want = mico.mic2_compress(stack, 4095, False)
     assert rc == 0
     ctx = mp.get_context("spawn")
@@ -57,8 +85,12 @@ def test_two_rank_mic2_assembly_matches_single_process(mico, synth):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, stack, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    mic2, pics = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got == want
+    assert mic2 == want
+    assert len(pics) == 5
+    for f in range(5):
+        rc, pw = mico.pics_compress(stack[f], 4095, 3, 2)
+        assert rc == 0 and pics[f] == pw
