@@ -173,7 +173,7 @@ def unit_codec_leg(mic, torch, d_px, units, steps, warmup, what):
             "roofline": roofline_block(kmean, raw, comp)}, kmean, offs
 
 
-def leg_wavelet(mic, torch, synth, dev, steps, warmup, nframes=48):
+def leg_wavelet(mic, torch, synth, dev, steps, warmup, nframes=256):
     """BASELINE config 3: WaveletV2SIMDRLEFSECompressU16, 5 levels, CR shape rows 2140 x cols 1760, frames side by side"""
     rows, cols = 2140, 1760
     d_px = synth.xr_like_batch_torch(nframes, cols=cols, rows=rows, depth=12, seed0=2000, noise=5.0, device=dev)   # = synth.cr_like noise

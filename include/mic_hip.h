@@ -63,6 +63,14 @@ const char *mic_hip_version(void);
  * out_cap >= MIC_HIP_FRAME_BOUND(width*height) is always sufficient: a frame whose every pixel escapes codes two tokens per
  * pixel, FSE only gives up (ErrIncompressible) at two bytes per token, and the NCount header of a 65536-symbol alphabet is < 128 KiB. */
 #define MIC_HIP_FRAME_BOUND(npx) (4 * (size_t)(npx) + 135168)
+/* The ONE capacity contract of every encoder below: a container's bound is the sum of its units' MIC_HIP_FRAME_BOUND plus its
+ * header and table.  (The reference C allocates 2*w*h + 4096 per unit, ojph/mic_compress_c.c:918, and its Go wrapper 4*len + 4096,
+ * ojph/mic_c.go:170; an all-escape frame needs the 4 bytes per pixel.)  Real frames code far below it: a caller that knows its
+ * data may pass less and handle MIC_ERR_CAPACITY. */
+#define MIC_HIP_PICS_BOUND(width, height, num_strips) \
+    (20 + 8 * (size_t)(num_strips) + 4 * (size_t)(width) * (size_t)(height) + 135168 * (size_t)(num_strips))
+#define MIC_HIP_MIC2_BOUND(width, height, nframes) \
+    (20 + (size_t)(nframes) * (8 + MIC_HIP_FRAME_BOUND((size_t)(width) * (size_t)(height))))
 int mic_hip_compress_frame(const uint16_t *pixels, int width, int height,
                            uint16_t max_value, int nstates,
                            uint8_t *out, size_t out_cap, size_t *out_len);
@@ -78,13 +86,24 @@ int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len,
  * ...FourState (fse4state.go:24), ...EightState (fse8state.go:31) and RANSCompressU16EightState
  * (rans8state.go:31): flavour = 1, 2, 4, 8 or 108 (rANS-8).  No fallback chain: the sentinels
  * MIC_ERR_USE_RLE / MIC_ERR_INCOMPRESSIBLE come back exactly where the Go functions return
- * ErrUseRLE / ErrIncompressible.  out_cap >= 2*n + 200000 is always sufficient. */
+ * ErrUseRLE / ErrIncompressible.  out_cap >= 2*n + 135168 is always sufficient (past two bytes per symbol the encoders
+ * return MIC_ERR_INCOMPRESSIBLE; the NCount header of a 65536-symbol alphabet is < 128 KiB). */
 int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour,
                              uint8_t *out, size_t out_cap, size_t *out_len);
+/* The same with the caller's ScratchU16.TableLog (fseu16.go:101-102): the value optimalTableLog starts from
+ * (fsecompressu16.go:480-518; 0 = the default 11, > 16 = MIC_ERR_ARGS like prepare(), fseu16.go:136-138).
+ * ScratchU16.MaxSymbolValue (fseu16.go:98-99) has no counterpart: the reference only defaults it, nothing reads it. */
+int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, int table_log,
+                                uint8_t *out, size_t out_cap, size_t *out_len);
 /* Replaces FSEDecompressU16Auto (fse2state.go:102-116): magic-byte dispatch over all five
  * flavours.  *out_n receives the number of symbols written. */
 int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len,
                                     uint16_t *out, size_t out_cap, size_t *out_n);
+/* The same with the caller's ScratchU16.DecompressLimit (fseu16.go:87-91; 0 = the default 2 GiB - 1): MIC_ERR_CAPACITY exactly
+ * where the reference returns "output size > DecompressLimit" -- it compares at every wrap of its 65536-symbol ring (and, for
+ * 1-state streams, at the end), so an N-state stream of `count` symbols fails iff floor(count / 65536) * 65536 >= limit. */
+int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t decompress_limit,
+                                  uint16_t *out, size_t out_cap, size_t *out_n);
 
 /* ---- batch: many independent units in one call (one cgo crossing, one launch chain) --- */
 /* Replaces the goroutine fan-out of parallelstrips.go:77-93 / :292-321, the frame loop of
@@ -116,7 +135,7 @@ int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs);
 /* ---- PICS container --------------------------------------------------------------------- */
 /* Replaces CompressParallelStrips{,4State,8State} (parallelstrips.go:55,128,199).
  * num_strips <= 0 is rejected with MIC_ERR_ARGS: the Go default (GOMAXPROCS) is a host
- * property and stays on the Go side.  out_cap >= 2*w*h + 4096 + 8*num_strips + 20. */
+ * property and stays on the Go side.  out_cap >= MIC_HIP_PICS_BOUND(width, height, num_strips) is always sufficient. */
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height,
                           uint16_t max_value, int num_strips, int nstates,
                           uint8_t *out, size_t out_cap, size_t *out_len);
@@ -149,7 +168,8 @@ int mic_hip_pica_decompress(const uint8_t *compressed, size_t compressed_len, ui
 
 /* ---- MIC2 container, independent frames --------------------------------------------------- */
 /* Replaces CompressMultiFrame(..., temporal=false) (multiframecompress.go:179) +
- * WriteMIC2 (multiframe.go:49).  frames = nframes*width*height u16, frame-major. */
+ * WriteMIC2 (multiframe.go:49).  frames = nframes*width*height u16, frame-major.  out_cap >= MIC_HIP_MIC2_BOUND(...) is always
+ * sufficient (also for the temporal form below). */
 int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nframes,
                           uint16_t max_value,
                           uint8_t *out, size_t out_cap, size_t *out_len);

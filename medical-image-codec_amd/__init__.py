@@ -84,7 +84,7 @@ class Unit(C.Structure):
 ABI_SYMBOLS = [
     "mic_hip_set_device", "mic_hip_device_name", "mic_hip_version",
     "mic_hip_compress_frame", "mic_hip_decompress_frame",
-    "mic_hip_fse_compress_u16", "mic_hip_fse_decompress_u16_auto",
+    "mic_hip_fse_compress_u16", "mic_hip_fse_decompress_u16_auto", "mic_hip_fse_compress_u16_ex", "mic_hip_fse_decompress_u16_ex",
     "mic_hip_compress_batch", "mic_hip_decompress_batch",
     "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
@@ -140,6 +140,8 @@ def lib() -> C.CDLL:
     L.mic_hip_decompress_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
     L.mic_hip_fse_compress_u16.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_fse_decompress_u16_auto.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_fse_compress_u16_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_fse_decompress_u16_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mic_hip_compress_batch.argtypes = [C.POINTER(EncJob), C.c_int]
     L.mic_hip_decompress_batch.argtypes = [C.POINTER(DecJob), C.c_int]
     L.mic_hip_pics_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_int,
@@ -218,25 +220,25 @@ def _bytes_arr(b) -> np.ndarray:
 
 
 # ------------------------------------------------------------------ bare FSE stage
-def fse_compress_u16(symbols, flavour: int = 2) -> bytes:
+def fse_compress_u16(symbols, flavour: int = 2, table_log: int = 0) -> bytes:
     """FSECompressU16 / TwoState / FourState / EightState (flavour 1/2/4/8) and
-    RANSCompressU16EightState (flavour 108)."""
+    RANSCompressU16EightState (flavour 108); table_log = ScratchU16.TableLog (fseu16.go:101-102; 0 = default)."""
     sym = _u16(symbols).reshape(-1)
     cap = sym.size * 2 + 200000
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
-    rc = lib().mic_hip_fse_compress_u16(sym.ctypes.data, sym.size, flavour, out.ctypes.data, cap, C.byref(n))
+    rc = lib().mic_hip_fse_compress_u16_ex(sym.ctypes.data, sym.size, flavour, table_log, out.ctypes.data, cap, C.byref(n))
     if rc:
         _raise(rc, "fse_compress_u16")
     return out[: n.value].tobytes()
 
 
-def fse_decompress_u16_auto(data, cap: int) -> np.ndarray:
-    """FSEDecompressU16Auto (fse2state.go:102-116)."""
+def fse_decompress_u16_auto(data, cap: int, decompress_limit: int = 0) -> np.ndarray:
+    """FSEDecompressU16Auto (fse2state.go:102-116); decompress_limit = ScratchU16.DecompressLimit (fseu16.go:87-91; 0 = default)."""
     c = _bytes_arr(data)
     out = np.empty(cap, dtype=np.uint16)
     n = C.c_size_t(0)
-    rc = lib().mic_hip_fse_decompress_u16_auto(c.ctypes.data, c.size, out.ctypes.data, cap, C.byref(n))
+    rc = lib().mic_hip_fse_decompress_u16_ex(c.ctypes.data, c.size, decompress_limit, out.ctypes.data, cap, C.byref(n))
     if rc:
         _raise(rc, "fse_decompress_u16_auto")
     return out[: n.value].copy()

@@ -353,8 +353,13 @@ int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len, u
 
 // ---- bare FSE stage (fsecompressu16.go:19, fse2state.go:22/102, fse4state.go:24, fse8state.go:31, rans8state.go:31)
 int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uint8_t *out, size_t out_cap, size_t *out_len) {
+    return mic_hip_fse_compress_u16_ex(symbols, n, flavour, 0, out, out_cap, out_len);
+}
+
+int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, int table_log, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!symbols || !out || !out_len) return MIC_ERR_ARGS;
     if (!(flavour == 1 || flavour == 2 || flavour == 4 || flavour == 8 || flavour == 108)) return MIC_ERR_ARGS;
+    if (table_log < 0 || table_log > MIC_MAX_TABLELOG) return MIC_ERR_ARGS;   // prepare(): "tableLog (%d) > maxTableLog (%d)", fseu16.go:136-138
     if (n <= 1) return MIC_ERR_INCOMPRESSIBLE;                          // first gate of every FSECompressU16* variant
     if (n > ((size_t)1 << 30)) return MIC_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -368,7 +373,7 @@ int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uin
     s->h_units.assign(1, MicUnit{});
     MicUnit &u = s->h_units[0];
     u.px_in = (const uint16_t *)s->io_px.p; u.w = (int32_t)n; u.h = 1; u.max_value = 0;
-    u.nstates = (uint16_t)flavour; u.mode = 1; u.no_fallback = 1;
+    u.nstates = (uint16_t)flavour; u.mode = 1; u.no_fallback = 1; u.req_tl = (uint32_t)table_log;
     s->fill_workspace(u, 0);
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4, s->stream));
@@ -386,6 +391,20 @@ int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uin
 }
 
 int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *out, size_t out_cap, size_t *out_n) {
+    return mic_hip_fse_decompress_u16_ex(in, in_len, 0, out, out_cap, out_n);
+}
+
+// ScratchU16.DecompressLimit (fseu16.go:87-91): the reference compares len(OutU16) with the limit every time its 65536-symbol ring
+// wraps (fse2state.go:249/283, fse4state.go:246/..., fse8state.go, fsedecompressu16.go:318/353) and, for 1-state streams, once more
+// at the end (fsedecompressu16.go:372): an N-state stream of `count` symbols fails iff floor(count / 65536) * 65536 >= limit,
+// a 1-state stream iff its symbol count >= limit.  0 = the default, 2 GiB - 1.
+int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t decompress_limit, uint16_t *out, size_t out_cap, size_t *out_n) {
+    if (decompress_limit < 0) return MIC_ERR_ARGS;
+    const uint64_t limit = decompress_limit ? (uint64_t)decompress_limit : ((2ull << 30) - 1);
+    if (in && in_len >= 6 && in[0] == 0xFF && (in[1] == 0x02 || in[1] == 0x04 || in[1] == 0x84 || in[1] == 0x08)) {
+        const uint64_t count = (uint64_t)in[2] | ((uint64_t)in[3] << 8) | ((uint64_t)in[4] << 16) | ((uint64_t)in[5] << 24);
+        if (count >= 65536 && (count / 65536) * 65536 >= limit) return MIC_ERR_CAPACITY;   // "output size (%d) > DecompressLimit (%d)"
+    }
     if (!in || !out || !out_n || in_len == 0) return in && in_len == 0 ? MIC_ERR_CORRUPT : MIC_ERR_ARGS;
     if (in_len > 0xFFFFFFF0ull || out_cap > ((size_t)1 << 30)) return MIC_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -409,6 +428,7 @@ int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *
     if ((rc = session_decode_finish(s, &st))) return rc;
     if (st != MIC_OK) return st;
     const size_t n = s->h_units[0].ntok;
+    if (s->h_units[0].flavour == 1 && (uint64_t)n >= limit) return MIC_ERR_CAPACITY;        // fsedecompressu16.go:372
     if (n > out_cap) return MIC_ERR_CAPACITY;
     if (n) HIP_TRY(hipMemcpy(out, s->h_units[0].tok, n * 2, hipMemcpyDeviceToHost));
     *out_n = n;

@@ -1010,7 +1010,7 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         hipLaunchKernelGGL((k_dec_tans_duo<8, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
         hipLaunchKernelGGL((k_dec_tans_duo<8, true>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);
     }
-    if (variant != 100) {
+    if (variant != 100 && !(variant == 0 && d_cls)) {                       // (the lane-per-state kernels cover every table size)
         launch_tans_lds<2, false>(d_units, n, stream, t, "k_dec_tans_lds<2,false,13>");
         launch_tans_lds<4, false>(d_units, n, stream, t, "k_dec_tans_lds<4,false,13>");
         launch_tans_lds<8, false>(d_units, n, stream, t, "k_dec_tans_lds<8,false,13>");

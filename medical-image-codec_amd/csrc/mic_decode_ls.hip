@@ -25,19 +25,25 @@
 // states once, and walks the RLE headers (rledecompressu16.go:59-85) on tiles it already holds in LDS.
 // Streams come from a compacted per-class list (k_dec_classify), so a launch only touches the units of its class.
 // LDS per stream: ring 1024 B | mirror dword + pad 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
+#include <type_traits>
 #include "mic_dev.h"
 #include "mic_launch.h"
 
-#define LS_SPW 3                                   // streams per wave
-#define LS_WAVES 3                                 // waves per group (one group per CU: the LDS is full)
-#define LS_TL 13                                   // largest tableLog served here
+// Table-size classes: streams per wave x waves per group are what the LDS holds of 2 << tableLog byte tables.
+//   tableLog <= 13: 3 x 3 = nine streams (159 120 bytes) | 14: 2 x 2 (136 256) | 15: 1 x 2 (134 736) | 16: 1 x 1 (132 368)
+// At tableLog 16 a nextState needs 17 bits when the table has 0-bit entries (zeroBits): those streams stay with k_dec_tans_gl.
 #define LS_RING 0u
 #define LS_STAGE 1040u
 #define LS_TAB 1296u
-#define LS_STREAM_BYTES (LS_TAB + (2u << LS_TL))   // 17680
-#define LS_LDS (LS_WAVES * LS_SPW * LS_STREAM_BYTES)   // 159120 of 163840
-#define LS_CLASSES 6                               // (N in 2,4,8) x (zeroBits)
-static_assert(LS_LDS <= 160 * 1024, "one group must fit a CU's LDS");
+#define LS_CLASSES MIC_CLS_CLASSES                 // 4 table-size classes x (N in 2,4,8) x (zeroBits)
+template <int TL> struct LsGeom {
+    static constexpr int SPW = TL <= 13 ? 3 : TL == 14 ? 2 : 1;           // streams per wave
+    static constexpr int WAVES = TL <= 13 ? 3 : TL == 16 ? 1 : 2;        // waves per group (one group per CU: the LDS is full)
+    static constexpr uint32_t STREAM_BYTES = LS_TAB + (2u << TL);
+    static constexpr uint32_t LDS = WAVES * SPW * STREAM_BYTES;
+    static_assert(LDS <= 160 * 1024, "one group must fit a CU's LDS");
+};
+#define LS_TL 13                                   // the nine-streams class
 
 typedef __attribute__((address_space(3))) uint32_t *ls_l32;
 typedef __attribute__((address_space(3))) uint16_t *ls_l16;
@@ -60,7 +66,8 @@ __device__ __forceinline__ uint64_t ls_rl64(uint64_t v, int lane) {
 }
 
 // Per-class lists of unit indices, in unit order: list[c * n + i], count[c].  Class = 2 * log2(N / 2) + zeroBits for the
-// N-state streams (rANS-8 decodes as 8-state) with tableLog <= 13; everything else is left to the kernels of mic_decode.hip.
+// N-state streams (rANS-8 decodes as 8-state), + 6 per table-size class (tableLog <= 13, 14, 15, 16); 1-state streams, very long
+// streams and tableLog-16 tables with 0-bit entries are left to the kernels of mic_decode.hip.
 // One group; the stream checks that need the blob (empty bitstream, zero end byte: bitreader.go:33-38) are made here.
 __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, int *list, int *count) {
     __shared__ uint32_t s_w[16][LS_CLASSES];
@@ -75,11 +82,12 @@ __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, in
             MicUnit &u = units[i];
             const uint32_t flav = u.flavour, tl = u.table_log;
             const uint32_t ns = (flav == 108) ? 8u : flav;
-            if (u.status == MICD_OK && u.ntok == 0 && (ns == 2 || ns == 4 || ns == 8) && tl >= MIC_MIN_TABLELOG && tl <= LS_TL) {
+            if (u.status == MICD_OK && u.ntok == 0 && (ns == 2 || ns == 4 || ns == 8) && tl >= MIC_MIN_TABLELOG && tl <= MIC_MAX_TABLELOG &&
+                !(tl == 16 && u.zero_bits)) {                               // (17-bit nextState: k_dec_tans_gl)
                 if (u.bits_off >= u.comp_len) u.status = MICD_ERR_CORRUPT;
                 else if (u.comp_len - u.bits_off < (1u << 27)) {            // 32-bit bit positions here; the serial kernel takes longer ones
                     if (u.comp_in[u.comp_len - 1] == 0) u.status = MICD_ERR_CORRUPT;
-                    else cls = (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
+                    else cls = (tl <= 13 ? 0 : (int)tl - 13) * 6 + (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
                 }
             }
         }
@@ -103,8 +111,10 @@ __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, in
     if (tid < LS_CLASSES) count[tid] = (int)s_base[tid];
 }
 
-template <int N, bool ZB>
-__global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, const int *list, const int *count_p) {
+template <int N, bool ZB, int TL>
+__global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit *units, const int *list, const int *count_p) {
+    constexpr int LS_SPW = LsGeom<TL>::SPW, LS_WAVES = LsGeom<TL>::WAVES;
+    constexpr uint32_t LS_STREAM_BYTES = LsGeom<TL>::STREAM_BYTES;
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout assumes dynamic LDS at 0
@@ -282,37 +292,40 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
         "v_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
 #define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_ADVANCE LS_ROUND_WINDOW
-    auto chunk2 = [&]() {
-        uint32_t e, w0, w1, c, nb, m, hi, pre, at;
-        if (ZB)                                                             // nbBits may be 0: the funnel shift would return the window
-            asm volatile(".set ls_off, 0\n\t"
-                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW     // the first round's reads, the chunk's first state
-                         ".rept 64\n\t"
-                         LS_ROUND_HEAD
-                         "v_alignbit_b32 %[hi], %[e], %[hi], %[m]\n\t"
-                         "v_cmp_eq_u32 vcc, 0, %[nb]\n\t"
-                         "v_cndmask_b32 %[st], %[hi], %[e], vcc\n\t"
-                         LS_ROUND_TAIL
-                         ".endr\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb),
-                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
-                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb)
-                         : "memory", "vcc");
-        else
-            asm volatile(".set ls_off, 0\n\t"
-                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW
-                         ".rept 64\n\t"
-                         LS_ROUND_HEAD
-                         "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t"
-                         LS_ROUND_TAIL
-                         ".endr\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb),
-                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
-                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb)
-                         : "memory");
-    };
+    // START / COUNT: stage byte offset of the first state and rounds of this piece (a whole chunk: 0, 64; tableLog 16 runs two halves
+    // with a ring refresh between them: at 16 bits a symbol a chunk may take 64 dwords off the 192 the ring has ahead)
+    // (a macro, not a lambda: clang does not capture through asm operands in a generic lambda)
+#define LS_CHUNK2(START_, COUNT_) do { \
+        uint32_t e, w0, w1, c, nb, m, hi, pre, at; \
+        if (ZB) \
+            asm volatile(".set ls_off, %[S]\n\t" \
+                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW \
+                         ".rept %[R]\n\t" \
+                         LS_ROUND_HEAD \
+                         "v_alignbit_b32 %[hi], %[e], %[hi], %[m]\n\t" \
+                         "v_cmp_eq_u32 vcc, 0, %[nb]\n\t" \
+                         "v_cndmask_b32 %[st], %[hi], %[e], vcc\n\t" \
+                         LS_ROUND_TAIL \
+                         ".endr\n\t" \
+                         "s_waitcnt lgkmcnt(0)" \
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb), \
+                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
+                         : "memory", "vcc"); \
+        else \
+            asm volatile(".set ls_off, %[S]\n\t" \
+                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW \
+                         ".rept %[R]\n\t" \
+                         LS_ROUND_HEAD \
+                         "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t" \
+                         LS_ROUND_TAIL \
+                         ".endr\n\t" \
+                         "s_waitcnt lgkmcnt(0)" \
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb), \
+                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
+                         : "memory"); \
+    } while (0)
     // ---- chunks of 128 symbols per stream ---------------------------------------------------------------------------
     constexpr uint32_t R = 128 / N;                                         // rounds per chunk
     const uint32_t chunks = count / 128u, rem = count - chunks * 128u;
@@ -329,7 +342,25 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
 #endif
     for (uint32_t ch = 0; ch < maxch; ch++) {
         if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
-        if (N == 2) chunk2();
+        if (TL == 16) {
+            if (N == 2) LS_CHUNK2(0, 32);
+            else {
+#pragma unroll
+                for (uint32_t r = 0; r < R / 2; r++) round(r * N * 2u);
+            }
+#pragma unroll
+            for (int j = 0; j < LS_SPW; j++) store_blk(j, s_blk[j] - 2, pf[j]);            // mid-chunk ring refresh
+#pragma unroll
+            for (int j = 0; j < LS_SPW; j++) {
+                s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
+                pf[j] = load_blk(j, s_blk[j] - 2);
+            }
+            if (N == 2) LS_CHUNK2(128, 32);
+            else {
+#pragma unroll
+                for (uint32_t r = R / 2; r < R; r++) round(r * N * 2u);
+            }
+        } else if (N == 2) LS_CHUNK2(0, 64);
         else {
 #pragma unroll
             for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
@@ -418,10 +449,12 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_dec_tans_ls(MicUnit *units, c
 // walks the stream itself and reports it.  Units that are not frames (bare FSE, WaveletV2, residual frames) are translated only.
 #define TR_THREADS 1024
 #define TR_TILE ((TR_THREADS - 64) * 8)
-__global__ void __launch_bounds__(TR_THREADS, 8) k_dec_translate(MicUnit *units) {
+template <int TRTL>   // 13: tables up to 2^13 states (two groups per CU) | 16: up to 2^16 (128 KiB of LDS: one group per CU)
+__global__ void __launch_bounds__(TR_THREADS, TRTL == 13 ? 8 : 4) k_dec_translate(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.walk_ok != 2) return;
-    __shared__ uint16_t s_sym[1 << LS_TL];
+    if ((TRTL == 13) != (u.table_log <= 13)) return;
+    __shared__ uint16_t s_sym[1 << TRTL];
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[2][TR_TILE + 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t size = 1u << u.table_log, ntok = u.ntok;
@@ -494,27 +527,39 @@ __global__ void __launch_bounds__(TR_THREADS, 8) k_dec_translate(MicUnit *units)
     }
 }
 
-template <int N, bool ZB>
-static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, int cls, hipStream_t stream) {
+template <int N, bool ZB, int TL>
+static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream) {
+    constexpr int cls = (TL <= 13 ? 0 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
+    constexpr int per = LsGeom<TL>::WAVES * LsGeom<TL>::SPW;
     static MicPerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS);
-    const unsigned groups = (unsigned)((n + LS_WAVES * LS_SPW - 1) / (LS_WAVES * LS_SPW));
-    hipLaunchKernelGGL((k_dec_tans_ls<N, ZB>), dim3(groups), dim3(64 * LS_WAVES), LS_LDS, stream, d_units,
+    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, LsGeom<TL>::LDS);
+    const unsigned groups = (unsigned)((n + per - 1) / per);
+    hipLaunchKernelGGL((k_dec_tans_ls<N, ZB, TL>), dim3(groups), dim3(64 * LsGeom<TL>::WAVES), LsGeom<TL>::LDS, stream, d_units,
                        d_list + (size_t)cls * (size_t)n, d_count + cls);
+}
+template <int TL>
+static void launch_ls_tl(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream, bool skip_first) {
+    if (!skip_first) launch_ls_class<2, false, TL>(d_units, n, d_list, d_count, stream);
+    if constexpr (TL < 16) launch_ls_class<2, true, TL>(d_units, n, d_list, d_count, stream);
+    launch_ls_class<4, false, TL>(d_units, n, d_list, d_count, stream);
+    if constexpr (TL < 16) launch_ls_class<4, true, TL>(d_units, n, d_list, d_count, stream);
+    launch_ls_class<8, false, TL>(d_units, n, d_list, d_count, stream);
+    if constexpr (TL < 16) launch_ls_class<8, true, TL>(d_units, n, d_list, d_count, stream);
 }
 
 // d_list: LS_CLASSES * n ints, d_count: LS_CLASSES ints (session workspace)
 void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t) {
     if (t) t->mark("k_dec_classify");
     hipLaunchKernelGGL(k_dec_classify, dim3(1), dim3(1024), 0, stream, d_units, n, d_list, d_count);
-    if (t) t->mark("k_dec_tans_ls<2,false>");
-    launch_ls_class<2, false>(d_units, n, d_list, d_count, 0, stream);
-    if (t) t->mark("k_dec_tans_ls<other>");
-    launch_ls_class<2, true>(d_units, n, d_list, d_count, 1, stream);
-    launch_ls_class<4, false>(d_units, n, d_list, d_count, 2, stream);
-    launch_ls_class<4, true>(d_units, n, d_list, d_count, 3, stream);
-    launch_ls_class<8, false>(d_units, n, d_list, d_count, 4, stream);
-    launch_ls_class<8, true>(d_units, n, d_list, d_count, 5, stream);
+    if (t) t->mark("k_dec_tans_ls<2,false,13>");
+    launch_ls_class<2, false, 13>(d_units, n, d_list, d_count, stream);
+    if (t) t->mark("k_dec_tans_ls<other,13>");
+    launch_ls_tl<13>(d_units, n, d_list, d_count, stream, true);
+    if (t) t->mark("k_dec_tans_ls<14..16>");
+    launch_ls_tl<14>(d_units, n, d_list, d_count, stream, false);
+    launch_ls_tl<15>(d_units, n, d_list, d_count, stream, false);
+    launch_ls_tl<16>(d_units, n, d_list, d_count, stream, false);
     if (t) t->mark("k_dec_translate");
-    hipLaunchKernelGGL(k_dec_translate, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    hipLaunchKernelGGL(k_dec_translate<13>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    hipLaunchKernelGGL(k_dec_translate<16>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
 }

@@ -34,6 +34,7 @@ struct MicUnit {
     uint16_t        nstates;  // encode: requested flavour 1/2/4/8, 108 = rANS-8
     uint32_t        mode;     // 0 = frame (Delta+RLE around the FSE stage), 1 = bare FSE: px_in / px_out hold u16 symbols, w = count
     uint32_t        no_fallback; // 1 = FSECompressU16* semantics (no N -> ... -> 1 chain)
+    uint32_t        req_tl;   // ScratchU16.TableLog of a bare FSE call (fseu16.go:101-102); 0 = the default 11
     uint32_t        pred;     // mode 0: 0 = avg(left, top) predictor, 1 = gradient-adaptive (deltagradrlecompressu16.go)
     // ---- per-unit workspace (HBM) ------------------------------------------------
     uint16_t *tok;            // RLE token stream (encode: produced, decode: FSE output)

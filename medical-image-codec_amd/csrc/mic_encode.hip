@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
     if (n <= 1 || (u.no_fallback && n <= (u.nstates == 108 ? 8u : (uint32_t)u.nstates) - 1)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
     if (u.max_count == n) { u.status = MICD_ERR_USE_RLE; return; }
     if (u.max_count == 1 || u.max_count < (n >> 15)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
-    u.table_log = mic_optimal_table_log(n, u.symbol_len);
+    u.table_log = mic_optimal_table_log(n, u.symbol_len, u.req_tl);
     const bool small = u.symbol_len <= ET_SMALL_SYMS && u.table_log <= ET_SMALL_TL;
     MicUnit v = u;                                  // working copy whose scratch arrays may point into LDS
     const uint32_t *hist = u.hist;
@@ -943,6 +943,19 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     const uint64_t gstart = 8ull * lead + woff + incl - mybits;            // first grid bit of this thread
     const uint64_t total_bits = (uint64_t)sym_bits + (uint64_t)N * tl + 1;
     const uint32_t total_bytes = (uint32_t)((total_bits + 7) >> 3);
+#ifdef MIC_GATE_REG
+    // diagnostic build: every thread forms the verdict from its own registers (the variant that misbehaved in round 1)
+    int rc_reg = MICD_OK;
+    if ((8ull * lead + total_bits + 63) / 32 >= words_cap) rc_reg = MICD_ERR_CAPACITY;
+    else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc_reg = MICD_ERR_INCOMPRESSIBLE;
+#ifdef MIC_GATE_REG2
+    if (rc_reg == MICD_ERR_CAPACITY) { total_bytes_out = total_bytes; rc_out = rc_reg; return; }   // (the verdict itself is used after the pack loop)
+#else
+    total_bytes_out = total_bytes; rc_out = rc_reg;
+    if (rc_reg != MICD_OK) return;
+#endif
+    const int rc = rc_reg; (void)rc;
+#else
     // the verdict goes through LDS so that every thread (and the caller) sees one value
     if (tid == 0) {
         int rc0 = MICD_OK;
@@ -955,6 +968,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     total_bytes_out = s_scan[TE_WAVES + 1];
     rc_out = rc;
     if (rc != MICD_OK) return;
+#endif
     MIC_STAMP_AT(u, 10);
     // ---- 4. pack -------------------------------------------------------------------------------------
     const uint32_t first_w = (uint32_t)(gstart >> 5);
@@ -1011,6 +1025,9 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         }
         words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
     }
+#ifdef MIC_GATE_REG2
+    total_bytes_out = total_bytes; rc_out = rc_reg;
+#endif
     MIC_STAMP_AT(u, 11);
 }
 

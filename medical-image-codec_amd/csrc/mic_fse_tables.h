@@ -10,8 +10,9 @@
 #include "mic_dev.h"
 
 // fsecompressu16.go:480-518 (optimalTableLog) with minTableLog (:465-472) inlined.
-__device__ inline uint32_t mic_optimal_table_log(uint32_t n, uint32_t symbol_len) {
-    uint8_t table_log = MIC_DEF_TABLELOG;
+// req = ScratchU16.TableLog as set by the caller (fseu16.go:101-102; 0 = defaultTablelog, :133-135)
+__device__ inline uint32_t mic_optimal_table_log(uint32_t n, uint32_t symbol_len, uint32_t req = 0) {
+    uint8_t table_log = req ? (uint8_t)req : (uint8_t)MIC_DEF_TABLELOG;
     uint32_t min_bits_src = mic_high_bits(n - 1) + 1;
     uint32_t min_bits_sym = mic_high_bits(symbol_len - 1) + 2;
     uint8_t min_bits = (uint8_t)(min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym);

@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
         else if (mm == n) rc = MICD_ERR_USE_RLE;
         else if (mm == 1 || mm < (n >> 15)) rc = MICD_ERR_INCOMPRESSIBLE;
         uint32_t tl = 0;
-        if (rc == MICD_OK) { tl = mic_optimal_table_log(n, ss); u.table_log = tl; }
+        if (rc == MICD_OK) { tl = mic_optimal_table_log(n, ss, u.req_tl); u.table_log = tl; }
         else u.status = rc;
         s_misc[0] = (uint32_t)rc; s_misc[1] = tl; s_misc[4] = ss; s_misc[5] = n;
     }

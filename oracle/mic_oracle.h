@@ -51,6 +51,8 @@ int mico_rle_decompress(const uint16_t *in, size_t n, uint16_t *out, size_t cap,
 /* ---- L1: FSE / tANS with a 16-bit alphabet ------------------------------ */
 /* nstates: 1 (fsecompressu16.go:19), 2 (fse2state.go:22), 4 (fse4state.go:24),
  * 8 (fse8state.go:31), 108 = rANS-8 (rans8state.go:31). */
+int mico_fse_compress_tl(const uint16_t *in, size_t n, int nstates, int table_log,
+                         uint8_t *out, size_t cap, size_t *out_len);
 int mico_fse_compress(const uint16_t *in, size_t n, int nstates,
                       uint8_t *out, size_t cap, size_t *out_len);
 /* FSEDecompressU16Auto (fse2state.go:102-116). */

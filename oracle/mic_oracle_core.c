@@ -331,6 +331,7 @@ typedef struct {
     size_t    n;           /* s.br.remain(): number of input symbols */
     uint32_t  symbol_len;
     uint8_t   table_log;   /* actualTableLog */
+    uint8_t   req_table_log; /* s.TableLog (fseu16.go:101-102); 0 = defaultTablelog */
     int       zero_bits;
     /* compression tables (fseu16.go:54-59) */
     uint16_t *table_symbol;
@@ -361,7 +362,7 @@ static uint32_t count_simple(fse_enc *s, const uint16_t *in, size_t n) {
 
 /* fsecompressu16.go:465-518 */
 static void optimal_table_log(fse_enc *s) {
-    uint8_t table_log = DEFAULT_TABLELOG; /* s.TableLog default, fseu16.go:133-135 */
+    uint8_t table_log = s->req_table_log ? s->req_table_log : DEFAULT_TABLELOG; /* s.TableLog, default fseu16.go:133-135 */
     uint32_t min_bits_src = high_bits((uint32_t)(s->n - 1)) + 1;
     uint32_t min_bits_sym = high_bits(s->symbol_len - 1) + 2;
     uint8_t min_bits = (uint8_t)(min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym);
@@ -677,13 +678,21 @@ int mico_fse_normalize(const uint16_t *in, size_t n, int32_t *norm, mico_fse_inf
  * fse4state.go:24-69, fse8state.go:31-77, rans8state.go:31-84. */
 int mico_fse_compress(const uint16_t *in, size_t n, int nstates,
                       uint8_t *out, size_t cap, size_t *out_len) {
+    return mico_fse_compress_tl(in, n, nstates, 0, out, cap, out_len);
+}
+
+/* the same with ScratchU16.TableLog set by the caller (fseu16.go:101-102, :133-138: 0 = default 11, > 16 is an error) */
+int mico_fse_compress_tl(const uint16_t *in, size_t n, int nstates, int table_log,
+                         uint8_t *out, size_t cap, size_t *out_len) {
     int lanes = (nstates == 108) ? 8 : nstates;
+    if (table_log < 0 || table_log > MAX_TABLELOG) return MICO_ERR_ARGS;   /* "tableLog (%d) > maxTableLog (%d)" */
     if (!(lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8)) return MICO_ERR_ARGS;
     if (n <= (size_t)(lanes - 1) || n <= 1) return MICO_ERR_INCOMPRESSIBLE;
     if (n > ((size_t)2 << 30) - 1) return MICO_ERR_ARGS;
     fse_enc s;
     int rc = fse_enc_prepare(&s, in, n);
     if (rc) return rc;
+    s.req_table_log = (uint8_t)table_log;
     uint32_t max_count = count_simple(&s, in, n);
     if ((size_t)max_count == n) { fse_enc_free(&s); return MICO_ERR_USE_RLE; }
     if (max_count == 1 || (size_t)max_count < (n >> 15)) { fse_enc_free(&s); return MICO_ERR_INCOMPRESSIBLE; }

@@ -75,6 +75,15 @@ def fse_compress(sym: np.ndarray, nstates: int):
     return rc, (out[: n.value].tobytes() if rc == 0 else b"")
 
 
+def fse_compress_tl(sym: np.ndarray, nstates: int, table_log: int):
+    """FSECompressU16* with ScratchU16.TableLog = table_log (fseu16.go:101-102)"""
+    sym = np.ascontiguousarray(sym, dtype=np.uint16)
+    out = np.empty(sym.size * 2 + 200000, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().mico_fse_compress_tl(_p(sym), C.c_size_t(sym.size), nstates, table_log, _p(out), C.c_size_t(out.size), C.byref(n))
+    return rc, (out[: n.value].tobytes() if rc == 0 else b"")
+
+
 def fse_decompress_auto(b: bytes, cap: int):
     a = np.frombuffer(bytes(b), dtype=np.uint8)
     out = np.empty(cap, dtype=np.uint16)

@@ -23,7 +23,7 @@ int main(void) {
     printf("device: %s, library %s\n", mic_hip_device_name(), mic_hip_version());
 
     /* CompressParallelStrips / DecompressParallelStrips */
-    size_t cap = npx * 2 + 4096 * (STRIPS + 1), clen = 0;
+    size_t cap = MIC_HIP_PICS_BOUND(W, H, STRIPS), clen = 0;            /* the one capacity contract, include/mic_hip.h */
     uint8_t *comp = malloc(cap);
     int rc = mic_hip_pics_compress(img, W, H, MAXV, STRIPS, 2, comp, cap, &clen);
     if (rc != MIC_OK) { fprintf(stderr, "pics_compress rc=%d\n", rc); return 1; }
@@ -41,9 +41,9 @@ int main(void) {
     uint8_t *outs[NJ];
     memset(ej, 0, sizeof ej); memset(dj, 0, sizeof dj);
     for (int i = 0; i < NJ; i++) {
-        outs[i] = malloc(npx / 2 + 4096);
+        outs[i] = malloc(MIC_HIP_FRAME_BOUND(npx / NJ));
         ej[i].pixels = img + (size_t)i * (H / NJ) * W; ej[i].width = W; ej[i].height = H / NJ; ej[i].max_value = MAXV; ej[i].nstates = 2;
-        ej[i].out = outs[i]; ej[i].out_cap = npx / 2 + 4096;
+        ej[i].out = outs[i]; ej[i].out_cap = MIC_HIP_FRAME_BOUND(npx / NJ);
     }
     rc = mic_hip_compress_batch(ej, NJ);
     if (rc != MIC_OK) { fprintf(stderr, "compress_batch rc=%d\n", rc); return 1; }

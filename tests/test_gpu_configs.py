@@ -161,6 +161,25 @@ def test_session_wsi_device_resident(mic, mico, synth, gpu_ready):
     sess.close()
 
 
+def test_wavelet_v2_streams_that_take_64_dwords_per_chunk(mic, mico, synth, gpu_ready):
+    """tableLog-16 streams can take 16 bits a symbol: 128 symbols = 64 dwords, more than the bit-window ring holds ahead of a chunk
+    unless it is refreshed mid-chunk (mic_decode_ls.hip).  Frame 2 of this batch is one (it decoded as corrupt before the refresh)."""
+    torch = pytest.importorskip("torch")
+    d_px = synth.xr_like_batch_torch(4, cols=1760, rows=2140, depth=12, seed0=2000, noise=5.0, device="cuda")
+    d_out = torch.zeros_like(d_px)
+    sess = mic.Session(4, 2 * 2140 * 1760 + 16)
+    d_streams, offs, st, applied = sess.wavelet_v2_encode(d_px.data_ptr(), 4, 2140, 1760, 5)
+    assert (st == 0).all()
+    dst = sess.wavelet_v2_decode(d_streams, offs, 4, 2140, 1760, applied, d_out.data_ptr())
+    assert (dst == 0).all() and torch.equal(d_out, d_px)
+    frame2 = d_px[2].cpu().numpy().view(np.uint16)
+    rc, want = mico.wavelet_v2_compress(frame2, 4095, 5)
+    host = torch.empty(int(offs[3] - offs[2]), dtype=torch.uint8, device="cuda")
+    mic.device_copy(host.data_ptr(), d_streams + int(offs[2]), host.numel())
+    assert rc == 0 and want[11:] == host.cpu().numpy().tobytes()
+    sess.close()
+
+
 def test_xr_batch_generator_on_the_device_equals_numpy(synth, gpu_ready):
     """bench.py's frames are made on the device: the same hash and the same float64 operations as synth.xr_like, bit for bit."""
     pytest.importorskip("torch")

@@ -161,6 +161,32 @@ def test_mic3_level_table_is_validated(mic, synth, gpu_ready):
             assert e.value.code == mic.MIC_ERR_CORRUPT
 
 
+def test_fse_scratch_knobs(mic, mico, gpu_ready):
+    """ScratchU16.TableLog and .DecompressLimit on the bare FSE calls (fseu16.go:87-102): the table log the caller asks for is where
+    optimalTableLog starts (fsecompressu16.go:480-518), and the limit is compared at every wrap of the 65536-symbol ring."""
+    tok = mico.delta_rle_compress(_mr(), int(_mr().max()))                   # 65 578 tokens
+    for ns in (1, 2, 4):
+        for tl in (0, 9, 12, 14, 16):
+            rc, want = mico.fse_compress_tl(tok, ns, tl)
+            assert rc == 0 and mic.fse_compress_u16(tok, ns, table_log=tl) == want
+            assert np.array_equal(mic.fse_decompress_u16_auto(want, len(tok) + 8), tok)
+    assert mic.fse_compress_u16(tok, 2, table_log=14)[6] & 15 == 14 - 5 and mic.fse_compress_u16(tok, 2)[6] & 15 == 13 - 5
+    with pytest.raises(mic.MicError) as e:
+        mic.fse_compress_u16(tok, 2, table_log=17)                           # "tableLog (17) > maxTableLog (16)"
+    assert e.value.code == mic.MIC_ERR_ARGS
+    blob = mic.fse_compress_u16(tok, 2)
+    assert np.array_equal(mic.fse_decompress_u16_auto(blob, len(tok) + 8, decompress_limit=65537), tok)   # one wrap at 65536 < limit
+    with pytest.raises(mic.MicError) as e:
+        mic.fse_decompress_u16_auto(blob, len(tok) + 8, decompress_limit=65536)
+    assert e.value.code == mic.MIC_ERR_CAPACITY
+    short = mic.fse_compress_u16(tok[:30000], 2)
+    assert len(mic.fse_decompress_u16_auto(short, 30008, decompress_limit=100)) == 30000        # no wrap, no check (N-state)
+    one = mic.fse_compress_u16(tok[:30000], 1)
+    with pytest.raises(mic.MicError):
+        mic.fse_decompress_u16_auto(one, 30008, decompress_limit=30000)      # 1-state: checked at the end, fsedecompressu16.go:372
+    assert len(mic.fse_decompress_u16_auto(one, 30008, decompress_limit=30001)) == 30000
+
+
 def test_mic2_matches_oracle(mic, mico, synth, gpu_ready):
     stack = synth.ct_stack(frames=6, size=128, depth=12, seed=21)
     rc, want = mico.mic2_compress(stack, 4095, False)

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 rocpd databases (ROCm 7 default output) into the small CSV summaries kept under profiles/.
 
-usage: prof_summary.py <trace.db> <fetch.db> <write.db> <out_prefix> <bench.json>
+usage: prof_summary.py <trace.db> <fetch.db> <write.db> <out_prefix> <bench.json> [<sq.db>]
   <out_prefix>_kernel_stats.csv : per kernel  calls, total/avg/min/max duration (us)   (rocprofv3 --kernel-trace --stats)
   <out_prefix>_pmc_fetch.csv    : per kernel  mean FETCH_SIZE (KB) per dispatch       (rocprofv3 --pmc FETCH_SIZE, own pass)
   <out_prefix>_pmc_write.csv    : per kernel  mean WRITE_SIZE (KB) per dispatch       (rocprofv3 --pmc WRITE_SIZE, own pass)
   <out_prefix>_traffic.json     : HBM bytes per launch of every kernel = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
        (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM / rocprofv3")
+  <out_prefix>_sq.csv           : per kernel  mean SQ counters per dispatch (own pass): wave cycles, instructions by kind, waits
 """
 import csv, json, sqlite3, sys
 
@@ -60,6 +61,17 @@ def main():
             "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; gfx950 FETCH_SIZE counts 128-byte reads as 64"}
     json.dump(out, open(prefix + "_traffic.json", "w"), indent=1)
     for r in ks[:12]: print(f"{r[3]:10.1f} us avg  x{r[1]:3d}  {r[0][:90]}")
+    if len(sys.argv) > 6:
+        cur = sqlite3.connect(sys.argv[6]).cursor()
+        rows = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                           "group by kernel_name, counter_name").fetchall()
+        names = sorted({r[1] for r in rows})
+        table = {}
+        for k, c, n, v in rows: table.setdefault(k, {})[c] = (n, v)
+        with open(prefix + "_sq.csv", "w", newline="") as f:
+            w = csv.writer(f); w.writerow(["kernel", "dispatches"] + names)
+            for k in sorted(table, key=lambda k: -table[k].get("SQ_WAVE_CYCLES", (0, 0))[1]):
+                w.writerow([short(k).replace(", ", ","), max(v[0] for v in table[k].values())] + [f"{table[k].get(c, (0, 0))[1]:.0f}" for c in names])
 
 
 if __name__ == "__main__":
