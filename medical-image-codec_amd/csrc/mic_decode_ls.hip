@@ -256,75 +256,74 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
             q += (int32_t)ntot;
         }
     };
-    // N = 2: the 64 rounds of a chunk as ONE hand-scheduled instruction stream.  A wave issues in order, one instruction per
-    // ~5 cycles whether it depends on its predecessor or not (tools/ubench_ls.hip), so what counts is the number of issue slots
-    // between the arrival of a table entry and the issue of the next look-up:
-    //   s_waitcnt, v_ffbh, v_sub (nbBits), v_sub (-nbBits), s_waitcnt (window), v_alignbit (window), v_and_dpp (the partner's
-    //   nbBits for the second state), v_lshl (window past them), v_alignbit (next state), v_lshl_add (its address), ds_read_u16
-    // = 11 slots + one LDS round trip (~55 cycles) = ~110 cycles per round; the stage store of the new state, the bit
-    // position and the next window's address and reads go behind that read, in the shadow of its latency.  (The compiler's
-    // own order put them in front of it: 15 slots.)  The two v_sub and the window v_alignbit also cover the two wait states
-    // a DPP read of a freshly written VGPR needs.  LDS queue at the top of a round, oldest first: entry, stage store, window lo,
-    // window hi.  Slot 0 of the stage takes the state the chunk starts from, round r stores the state it produces in slot r + 1.
+    // N = 2: the 64 rounds of a chunk as ONE hand-scheduled instruction stream.  A lone wave issues in order, one instruction per
+    // ~6 cycles whether it depends on its predecessor or not (tools/ubench_ls.hip), and a round is bound by that: what counts is
+    // the number of instructions.  Sixteen per round:
+    //   head  s_waitcnt (entry) | v_ffbh | v_sub: m = -nbBits | ds_write_b16: the state the round starts from, to the stage |
+    //         s_waitcnt (window) | v_alignbit: the 32-bit window at q | v_and_dpp: the partner's m for the second state, 0 for the
+    //         first | v_alignbit(window, window, that): a ROTATE, so the first state (shift 0) keeps the window and the second sees
+    //         it past the first one's bits (what wraps into the low bits is never read: two states take <= 26 of the 32) |
+    //         v_alignbit(entry, window', m): the next state | v_lshl_add: its table address | ds_read_u16
+    //   tail  v_add_dpp: minus the round's bits | v_add: bit position | v_bfe + v_lshl_add: ring address | ds_read2_b32 (window)
+    //         -- behind the look-up, in the shadow of its latency.
+    // 115 cycles per round (tools/ubench_ls.hip: the table look-up alone, entry -> ffbh -> sub -> alignbit -> lshl_add -> entry, takes
+    // 80: ~60 of LDS latency and ~4.3 per instruction, DPP, s_waitcnt and LDS issue alike; the stage store in the tail instead:
+    // 122, because the window read then leaves later and the head waits for it; v_and_dpp in front of the window wait: 118).
+    // The stage store, the s_waitcnt and the window v_alignbit cover the two wait states a DPP read of a freshly written VGPR
+    // needs.  LDS queue at the top of a round, oldest first: entry, window.  v62 / v63 take the window's two dwords (a 64-bit asm
+    // operand cannot be split into its halves, fixed registers can).
 #define LS_ROUND_LOOKUP \
         "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\t" \
         "ds_read_u16 %[e], %[at]\n\t"
-#define LS_ROUND_STAGE \
-        ".if ls_off < 256\n\t" \
-        "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
-        ".endif\n\t" \
-        ".set ls_off, ls_off+4\n\t"
 #define LS_ROUND_ADVANCE \
-        "v_add_u32_dpp %[pre], %[nb], %[nb] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_sub_u32 %[q], %[q], %[pre]\n\t"
+        "v_add_u32_dpp %[pre], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32 %[q], %[q], %[pre]\n\t"
 #define LS_ROUND_WINDOW \
         "v_bfe_u32 %[at], %[q], 5, 8\n\t" \
         "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
-        "ds_read_b32 %[w0], %[at]\n\t" \
-        "ds_read_b32 %[w1], %[at] offset:4\n\t"
+        "ds_read2_b32 v[62:63], %[at] offset1:1\n\t"
 #define LS_ROUND_HEAD \
-        "s_waitcnt lgkmcnt(3)\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
         "v_ffbh_u32 %[c], %[e]\n\t" \
-        "v_sub_u32 %[nb], %[c], %[C]\n\t" \
         "v_sub_u32 %[m], %[C], %[c]\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "v_alignbit_b32 %[hi], %[w1], %[w0], %[q]\n\t" \
-        "v_and_b32_dpp %[pre], %[nb], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_lshlrev_b32 %[hi], %[pre], %[hi]\n\t"
-#define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_ADVANCE LS_ROUND_WINDOW
+        "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
+        ".set ls_off, ls_off+4\n\t" \
+        "s_waitcnt lgkmcnt(1)\n\t" \
+        "v_alignbit_b32 %[hi], v63, v62, %[q]\n\t" \
+        "v_and_b32_dpp %[pre], %[m], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_alignbit_b32 %[hi], %[hi], %[hi], %[pre]\n\t"
+#define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_ADVANCE LS_ROUND_WINDOW
     // START / COUNT: stage byte offset of the first state and rounds of this piece (a whole chunk: 0, 64; tableLog 16 runs two halves
     // with a ring refresh between them: at 16 bits a symbol a chunk may take 64 dwords off the 192 the ring has ahead)
     // (a macro, not a lambda: clang does not capture through asm operands in a generic lambda)
 #define LS_CHUNK2(START_, COUNT_) do { \
-        uint32_t e, w0, w1, c, nb, m, hi, pre, at; \
+        uint32_t e, c, m, hi, pre, at; \
         if (ZB) \
             asm volatile(".set ls_off, %[S]\n\t" \
-                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW \
+                         LS_ROUND_LOOKUP LS_ROUND_WINDOW \
                          ".rept %[R]\n\t" \
                          LS_ROUND_HEAD \
                          "v_alignbit_b32 %[hi], %[e], %[hi], %[m]\n\t" \
-                         "v_cmp_eq_u32 vcc, 0, %[nb]\n\t" \
+                         "v_cmp_eq_u32 vcc, 0, %[m]\n\t" \
                          "v_cndmask_b32 %[st], %[hi], %[e], vcc\n\t" \
                          LS_ROUND_TAIL \
                          ".endr\n\t" \
                          "s_waitcnt lgkmcnt(0)" \
-                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb), \
-                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
                          : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
-                         : "memory", "vcc"); \
+                         : "memory", "vcc", "v62", "v63"); \
         else \
             asm volatile(".set ls_off, %[S]\n\t" \
-                         LS_ROUND_LOOKUP LS_ROUND_STAGE LS_ROUND_WINDOW \
+                         LS_ROUND_LOOKUP LS_ROUND_WINDOW \
                          ".rept %[R]\n\t" \
                          LS_ROUND_HEAD \
                          "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t" \
                          LS_ROUND_TAIL \
                          ".endr\n\t" \
                          "s_waitcnt lgkmcnt(0)" \
-                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [w0] "=&v"(w0), [w1] "=&v"(w1), [c] "=&v"(c), [nb] "=&v"(nb), \
-                           [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
+                         : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
                          : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
-                         : "memory"); \
+                         : "memory", "v62", "v63"); \
     } while (0)
     // ---- chunks of 128 symbols per stream ---------------------------------------------------------------------------
     constexpr uint32_t R = 128 / N;                                         // rounds per chunk
@@ -440,17 +439,18 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 }
 
 // ==========================================================================================
-// States -> symbols, and the RLE header walk.  One group of 1024 threads per unit that k_dec_tans_ls decoded (walk_ok == 2):
-// the unit's symbol table (tableSymbol of each state, <= 16 KiB) sits in LDS, waves 1-15 stream the states through it in tiles
-// of 7680 (16 bytes in, eight LDS look-ups, 16 bytes out, in place) and leave each translated tile in LDS as well, where wave 0
+// States -> symbols, and the RLE header walk.  One group of 256 threads per unit that k_dec_tans_ls decoded (walk_ok == 2):
+// the unit's symbol table (tableSymbol of each state, <= 16 KiB) sits in LDS, waves 1-3 stream the states through it in tiles
+// of 1536 (16 bytes in, eight LDS look-ups, 16 bytes out, in place) and leave each translated tile in LDS as well, where wave 0
 // follows the linked list of RLE headers through it (rledecompressu16.go:59-85: a header <= midCount is a run of one value, a
 // larger one a literal chunk) one tile behind, from a 64-token window and v_readlane -- no dependent HBM read per header.
 // Stop and error rules are those of the walkers in mic_decode.hip: on an error the segments are dropped and k_dec_pixels_wg
 // walks the stream itself and reports it.  Units that are not frames (bare FSE, WaveletV2, residual frames) are translated only.
-#define TR_THREADS 1024
+#define TR_THREADS 256                            // one walker wave + three translating waves: seven groups (walkers) per CU -- the walk is
+                                                  // serial per unit, and on run-dense streams (WSI planes) it is what a unit waits for
 #define TR_TILE ((TR_THREADS - 64) * 8)
 template <int TRTL>   // 13: tables up to 2^13 states (two groups per CU) | 16: up to 2^16 (128 KiB of LDS: one group per CU)
-__global__ void __launch_bounds__(TR_THREADS, TRTL == 13 ? 8 : 4) k_dec_translate(MicUnit *units) {
+__global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.walk_ok != 2) return;
     if ((TRTL == 13) != (u.table_log <= 13)) return;

@@ -75,6 +75,122 @@ __global__ void __launch_bounds__(192) k_round(const uint16_t *tab, uint32_t *ou
     if (st == 0xFFFFFFFFu) out[1] = st + q;
 }
 
+// Bare chain (entry -> ffbh -> sub -> alignbit -> lshl_add -> entry) plus X extra DEPENDENT instructions of one kind in the chain:
+// K: 0 none | 1 v_alignbit_b32 | 2 v_and_b32_dpp quad_perm | 3 v_lshlrev_b32 | 4 s_waitcnt (satisfied) | 5 v_add_u32 | 6 v_mov_b32_dpp
+template <int K, int X>
+__global__ void __launch_bounds__(64) k_cost(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t i = lane; i < 4096; i += 64) s_mem[(TAB >> 2) + i] = ((const uint32_t *)tab)[i];
+    __syncthreads();
+    const uint32_t cb = TAB - 2u * 8192u, C = 31u - 13u, ones = ~0u, zero = 0;
+    uint32_t st = 8192u + ((out[0] + 17u * lane) & 8191u), q = 0x12345678u, e, c, m, at;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int ch = 0; ch < chunks; ch++) {
+        asm volatile(
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".rept 64\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_ffbh_u32 %[c], %[e]\n\t"
+            "v_sub_u32 %[m], %[C], %[c]\n\t"
+            ".rept %[X]\n\t"
+            ".if %[K] == 1\n\tv_alignbit_b32 %[m], %[zero], %[m], %[zero]\n\t"
+            ".elseif %[K] == 2\n\tv_and_b32_dpp %[m], %[m], %[ones] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            ".elseif %[K] == 3\n\tv_lshlrev_b32 %[m], %[zero], %[m]\n\t"
+            ".elseif %[K] == 4\n\ts_waitcnt lgkmcnt(0)\n\t"
+            ".elseif %[K] == 5\n\tv_add_u32 %[m], %[m], %[zero]\n\t"
+            ".elseif %[K] == 6\n\tv_mov_b32_dpp %[m], %[m] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            ".endif\n\t"
+            ".endr\n\t"
+            "v_alignbit_b32 %[st], %[e], %[q], %[m]\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".endr\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [st] "+v"(st), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [at] "=&v"(at)
+            : [C] "v"(C), [cb] "v"(cb), [q] "v"(q), [ones] "v"(ones), [zero] "v"(zero), [K] "n"(K), [X] "n"(X) : "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x] = t1 - t0;
+    if (st == 0xFFFFFFFFu) out[1] = st;
+}
+template <int K, int X> int cost(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int chunks) {
+    hipLaunchKernelGGL((k_cost<K, X>), dim3(1), dim3(64), 20 * 1024, 0, d_tab, d_out, chunks, d_cyc);
+    CK(hipDeviceSynchronize());
+    unsigned long long c = 0;
+    CK(hipMemcpy(&c, d_cyc, 8, hipMemcpyDeviceToHost));
+    printf("chain + %d x %-28s %6.1f cycles/round\n", X, name, (double)c / ((double)chunks * 64.0));
+    return 0;
+}
+
+// Candidate rounds of the m-only form (v_sub m = -nbBits; rotate instead of shift).  W: 0 ds_read2_b32 window | 1 two ds_read_b32.
+// P: where the stage store sits: 0 tail (stores the new state) | 1 head, behind v_sub (stores the round's start state) |
+//    2 as 1, and v_and_dpp moved in front of the window wait (s_nop for the DPP hazard).
+template <int W, int P>
+__global__ void __launch_bounds__(192) k_cand(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t g = lane / 2; if (g >= 3) g = 0;
+    const uint32_t k = lane & 1;
+    const uint32_t sbase = (wv * 3 + g) * STREAM_BYTES;
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t tb = ((wv * 3 + j) * STREAM_BYTES + TAB) >> 2;
+        for (uint32_t i = lane; i < 4096; i += 64) s_mem[tb + i] = ((const uint32_t *)tab)[i];
+        const uint32_t rb = ((wv * 3 + j) * STREAM_BYTES) >> 2;
+        for (uint32_t i = lane; i < 260; i += 64) s_mem[rb + i] = 0x9E3779B9u * (i + 1 + j);
+    }
+    __syncthreads();
+    const uint32_t cb = sbase + TAB - 2u * 8192u, C = 31u - 13u, ringb = sbase, stgb = sbase + STAGE + 2u * k;
+    const uint32_t mk1 = k ? ~0u : 0u;
+    uint32_t st = 8192u + ((out[0] + 17u * lane) & 8191u), q = 1u << 20;
+    uint32_t e, c, m, hi, pre, at;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int ch = 0; ch < chunks; ch++) {
+        asm volatile(
+            ".set ls_off, 0\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".if %[P] == 0\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.set ls_off, ls_off+4\n\t.endif\n\t"
+            "v_bfe_u32 %[at], %[q], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            ".if %[W] == 0\n\tds_read2_b32 v[62:63], %[at] offset1:1\n\t.else\n\tds_read_b32 v62, %[at]\n\tds_read_b32 v63, %[at] offset:4\n\t.endif\n\t"
+            ".rept 64\n\t"
+            // wait for the entry: queue (oldest first) P0: e, stage, window(1 or 2) ; P1/P2: e, window(1 or 2)
+            ".if %[P] == 0\n\t.if %[W] == 0\n\ts_waitcnt lgkmcnt(2)\n\t.else\n\ts_waitcnt lgkmcnt(3)\n\t.endif\n\t"
+            ".else\n\t.if %[W] == 0\n\ts_waitcnt lgkmcnt(1)\n\t.else\n\ts_waitcnt lgkmcnt(2)\n\t.endif\n\t.endif\n\t"
+            "v_ffbh_u32 %[c], %[e]\n\t"
+            "v_sub_u32 %[m], %[C], %[c]\n\t"
+            ".if %[P] != 0\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.set ls_off, ls_off+4\n\t.endif\n\t"
+            ".if %[P] == 2\n\ts_nop 0\n\tv_and_b32_dpp %[pre], %[m], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t.endif\n\t"
+            // wait for the window: P0: only older ops matter -> 0 ; P1/P2: the stage store is younger than the window
+            ".if %[P] == 0\n\ts_waitcnt lgkmcnt(0)\n\t.else\n\ts_waitcnt lgkmcnt(1)\n\t.endif\n\t"
+            "v_alignbit_b32 %[hi], v63, v62, %[q]\n\t"
+            ".if %[P] != 2\n\tv_and_b32_dpp %[pre], %[m], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t.endif\n\t"
+            "v_alignbit_b32 %[hi], %[hi], %[hi], %[pre]\n\t"
+            "v_alignbit_b32 %[st], %[e], %[hi], %[m]\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            ".if %[P] == 0\n\t.if ls_off < 256\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.endif\n\t.set ls_off, ls_off+4\n\t.endif\n\t"
+            "v_add_u32_dpp %[pre], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_u32 %[q], %[q], %[pre]\n\t"
+            "v_bfe_u32 %[at], %[q], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            ".if %[W] == 0\n\tds_read2_b32 v[62:63], %[at] offset1:1\n\t.else\n\tds_read_b32 v62, %[at]\n\tds_read_b32 v63, %[at] offset:4\n\t.endif\n\t"
+            ".endr\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at)
+            : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [W] "n"(W), [P] "n"(P)
+            : "memory", "v62", "v63");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * 3 + wv] = t1 - t0;
+    if (st == 0xFFFFFFFFu) out[1] = st + q;
+}
+template <int W, int P> int cand(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int chunks) {
+    CK(hipFuncSetAttribute((const void *)k_cand<W, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * STREAM_BYTES));
+    hipLaunchKernelGGL((k_cand<W, P>), dim3(1), dim3(192), 9 * STREAM_BYTES, 0, d_tab, d_out, chunks, d_cyc);
+    CK(hipDeviceSynchronize());
+    unsigned long long c[3];
+    CK(hipMemcpy(c, d_cyc, 24, hipMemcpyDeviceToHost));
+    printf("%-70s %6.1f cycles/round\n", name, (double)c[1] / ((double)chunks * 64.0));
+    return 0;
+}
+
 template <int V> int run(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int blocks, int waves, int chunks) {
     CK(hipFuncSetAttribute((const void *)k_round<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * STREAM_BYTES));
     hipLaunchKernelGGL(k_round<V>, dim3(blocks), dim3(64 * waves), 9 * STREAM_BYTES, 0, d_tab, d_out, chunks, d_cyc);
@@ -97,7 +213,20 @@ int main() {
     CK(hipMalloc(&d_tab, 16384)); CK(hipMalloc(&d_out, 64)); CK(hipMalloc(&d_cyc, 8 * 3 * 1024));
     CK(hipMemcpy(d_tab, tab.data(), 16384, hipMemcpyHostToDevice)); CK(hipMemset(d_out, 0, 64));
     const int chunks = 400;
-    for (int blocks : {1, 256}) {
+    cand<0, 0>("m-only round, ds_read2 window, stage store in the tail (shipped)", d_tab, d_out, d_cyc, chunks);
+    cand<1, 0>("m-only round, two ds_read_b32, stage store in the tail", d_tab, d_out, d_cyc, chunks);
+    cand<0, 1>("m-only round, ds_read2 window, stage store in the head", d_tab, d_out, d_cyc, chunks);
+    cand<1, 1>("m-only round, two ds_read_b32, stage store in the head", d_tab, d_out, d_cyc, chunks);
+    cand<0, 2>("... and v_and_dpp in front of the window wait", d_tab, d_out, d_cyc, chunks);
+    cand<1, 2>("... the same with two ds_read_b32", d_tab, d_out, d_cyc, chunks);
+    cost<0, 0>("(nothing)", d_tab, d_out, d_cyc, chunks);
+    cost<1, 1>("v_alignbit_b32", d_tab, d_out, d_cyc, chunks); cost<1, 4>("v_alignbit_b32", d_tab, d_out, d_cyc, chunks);
+    cost<2, 1>("v_and_b32_dpp", d_tab, d_out, d_cyc, chunks); cost<2, 4>("v_and_b32_dpp", d_tab, d_out, d_cyc, chunks);
+    cost<3, 1>("v_lshlrev_b32", d_tab, d_out, d_cyc, chunks); cost<3, 4>("v_lshlrev_b32", d_tab, d_out, d_cyc, chunks);
+    cost<4, 1>("s_waitcnt (satisfied)", d_tab, d_out, d_cyc, chunks); cost<4, 4>("s_waitcnt (satisfied)", d_tab, d_out, d_cyc, chunks);
+    cost<5, 1>("v_add_u32", d_tab, d_out, d_cyc, chunks); cost<5, 4>("v_add_u32", d_tab, d_out, d_cyc, chunks);
+    cost<6, 1>("v_mov_b32_dpp", d_tab, d_out, d_cyc, chunks); cost<6, 4>("v_mov_b32_dpp", d_tab, d_out, d_cyc, chunks);
+    for (int blocks : {1}) {
         run<0>("shipped round", d_tab, d_out, d_cyc, blocks, 3, chunks);
         run<0>("shipped round, one wave per CU", d_tab, d_out, d_cyc, blocks, 1, chunks);
         run<1>("no stage store", d_tab, d_out, d_cyc, blocks, 3, chunks);
