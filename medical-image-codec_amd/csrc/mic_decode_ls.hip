@@ -24,22 +24,29 @@
 // cycles per chunk; stamps: tools/time_dec.py on an LS_STAMP build).  k_dec_translate has the table in LDS, streams the
 // states once, and walks the RLE headers (rledecompressu16.go:59-85) on tiles it already holds in LDS.
 // Streams come from a compacted per-class list (k_dec_classify), so a launch only touches the units of its class.
-// LDS per stream: ring 1024 B | mirror dword + pad 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
+// LDS per stream: ring 1024 B | 2 mirror dwords + pad, 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
 #include <type_traits>
 #include "mic_dev.h"
 #include "mic_launch.h"
 
 // Table-size classes: streams per wave x waves per group are what the LDS holds of 2 << tableLog byte tables.
-//   tableLog <= 13: 3 x 3 = nine streams (159 120 bytes) | 14: 2 x 2 (136 256) | 15: 1 x 2 (134 736) | 16: 1 x 1 (132 368)
+//   tableLog <= 13: 3 x 3 = nine streams (159 120 bytes) | 14: 2 x 2 (136 256) | 15: 1 x 2 (134 736) | 16: 1 x 1 (133 392)
 // At tableLog 16 a nextState needs 17 bits when the table has 0-bit entries (zeroBits): those streams stay with k_dec_tans_gl.
 #define LS_RING 0u
-#define LS_STAGE 1040u
-#define LS_TAB 1296u
 #define LS_CLASSES MIC_CLS_CLASSES                 // 4 table-size classes x (N in 2,4,8) x (zeroBits)
 template <int TL> struct LsGeom {
     static constexpr int SPW = TL <= 13 ? 3 : TL == 14 ? 2 : 1;           // streams per wave
     static constexpr int WAVES = TL <= 13 ? 3 : TL == 16 ? 1 : 2;        // waves per group (one group per CU: the LDS is full)
-    static constexpr uint32_t STREAM_BYTES = LS_TAB + (2u << TL);
+    // The bit window's ring: blocks of 64 dwords.  A chunk of 128 symbols takes at most 4 * tableLog dwords off it (+ 2 the window
+    // reads reach below the position): under a block up to tableLog 15, so three blocks stored (the position's, one above, one below)
+    // and a fourth in flight do; at tableLog 16 a chunk can take a whole block, so the ring is twice as long and runs a block deeper.
+    static constexpr int RING_BLOCKS = TL == 16 ? 8 : 4;
+    static constexpr int DEPTH = TL == 16 ? 3 : 2;                        // the block in flight is the position's block - DEPTH
+    static constexpr int RING_BITS = TL == 16 ? 9 : 8;                    // dword index bits
+    static constexpr uint32_t MIRROR = 256u * RING_BLOCKS;                // two mirror dwords (slots 0, 1) + two pad dwords
+    static constexpr uint32_t STAGE = MIRROR + 16u;                       // 128 u16 states of a chunk
+    static constexpr uint32_t TAB = STAGE + 256u;
+    static constexpr uint32_t STREAM_BYTES = TAB + (2u << TL);
     static constexpr uint32_t LDS = WAVES * SPW * STREAM_BYTES;
     static_assert(LDS <= 160 * 1024, "one group must fit a CU's LDS");
 };
@@ -114,7 +121,8 @@ __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, in
 template <int N, bool ZB, int TL>
 __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit *units, const int *list, const int *count_p) {
     constexpr int LS_SPW = LsGeom<TL>::SPW, LS_WAVES = LsGeom<TL>::WAVES;
-    constexpr uint32_t LS_STREAM_BYTES = LsGeom<TL>::STREAM_BYTES;
+    constexpr uint32_t LS_STREAM_BYTES = LsGeom<TL>::STREAM_BYTES, LS_STAGE = LsGeom<TL>::STAGE, LS_TAB = LsGeom<TL>::TAB, LS_MIRROR = LsGeom<TL>::MIRROR;
+    constexpr int LS_RB = LsGeom<TL>::RING_BLOCKS, LS_DEPTH = LsGeom<TL>::DEPTH, LS_RBITS = LsGeom<TL>::RING_BITS;
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_mem != 0u) return;   // layout assumes dynamic LDS at 0
@@ -122,8 +130,12 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     const int slot0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * LS_WAVES + (int)wv) * LS_SPW);   // (wave-uniform, provably so: descriptors below)
     if (slot0 >= n_cls) return;                                             // waves share nothing and never meet at a barrier
     // ---- roles ----------------------------------------------------------------------------------------------------
-    const uint32_t k = lane % N;                                            // state of the chain this lane runs
-    uint32_t g = lane / N; if (g >= LS_SPW) g = 0;                          // its stream; surplus lanes clone stream 0
+    // N = 4 gives every stream a DPP row of 16 lanes (states in lanes 0-3, the other twelve are clones that sit out the chunks):
+    // row_shr then stops at the stream's first lane by itself, and the prefix sum of a round is two instructions
+    constexpr int LS_LS = N == 4 ? 16 : N;                                  // lanes from one stream to the next
+    const uint32_t k = (lane % LS_LS) % N;                                  // state of the chain this lane runs
+    const bool real = lane % LS_LS < N && lane < LS_SPW * LS_LS;            // (not a clone inside a stream's row, nor a surplus lane)
+    uint32_t g = lane / LS_LS; if (g >= LS_SPW) g = 0;                      // its stream; surplus lanes clone stream 0
     const bool have = slot0 + (int)g < n_cls;                               // the last wave of a class may hold fewer streams
     const uint32_t gs = have ? g : 0;                                       // absent streams run on stream 0's table (every access in range)
     const MicUnit &u = units[list[slot0 + (int)gs]];
@@ -136,7 +148,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 #pragma unroll 1
     for (int j = 0; j < LS_SPW; j++) {
         if (slot0 + j >= n_cls) break;
-        const int src = j * N;                                              // a lane that holds stream j's values
+        const int src = j * LS_LS;                                          // a lane that holds stream j's values
         const uint32_t sz = ls_rl(size, src);
         const uint32_t *dt = (const uint32_t *)(uintptr_t)ls_rl64((uint64_t)(uintptr_t)u.tt_nb, src);
         const uint32_t tb = (wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_TAB;
@@ -161,15 +173,16 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     // a block of the stream that lies (partly) outside it reads as zeros and a store behind a stream's last whole chunk is
     // dropped by the range check, so the per-chunk upkeep below has no branch at all (a taken scalar branch costs a wave
     // 30-45 cycles, and the compiler-predicated form of this upkeep had fifteen of them: 1700 cycles per chunk, stamped).
-    bool s_have[LS_SPW]; uint64_t s_out[LS_SPW]; int32_t s_blk[LS_SPW]; uint32_t s_chunks[LS_SPW];
+    bool s_have[LS_SPW]; uint64_t s_out[LS_SPW]; int32_t s_blk[LS_SPW], s_pfb[LS_SPW]; uint32_t s_chunks[LS_SPW];
     __amdgpu_buffer_rsrc_t rs_in[LS_SPW], rs_out[LS_SPW];
 #pragma unroll
     for (int j = 0; j < LS_SPW; j++) {
-        const int src = j * N;
+        const int src = j * LS_LS;
         s_have[j] = slot0 + j < n_cls;
         s_out[j] = ls_rl64((uint64_t)(uintptr_t)u.tok, src);
         s_chunks[j] = ls_rl(count, src) / 128u;
-        s_blk[j] = ((int32_t)ls_rl((uint32_t)q, src) >> 5) >> 6;
+        s_blk[j] = ((int32_t)ls_rl((uint32_t)(q - (int32_t)(N * tl)), src) >> 5) >> 6;   // block of the position BEHIND the initial states (N * tableLog
+                                                                            // bits at most: a chunk then never moves the position by more than one block)
         const uint32_t in_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_have[j] ? ((uint32_t)((int32_t)ls_rl((uint32_t)top_dw, src) + 1)) * 4u : 0u));
         const uint32_t out_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_have[j] ? s_chunks[j] * 256u : 0u));
         rs_in[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)ls_rl64(gaddr, src), 0, (int)in_bytes, 0x00020000);
@@ -178,21 +191,21 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     auto load_blk = [&](int j, int32_t b) -> uint32_t {                    // dword `lane` of block b of stream j, zero outside the stream
         return __builtin_amdgcn_raw_buffer_load_b32(rs_in[j], (b * 64 + (int32_t)lane) * 4, 0, 2);   // (a negative offset is out of range too); nt: streamed once
     };
-    const uint32_t mirror_sel = (lane == 0) ? 4u : 0u;
     auto store_blk = [&](int j, int32_t b, uint32_t v) {
         const uint32_t rb = (wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_RING;
-        *(ls_l32)(uintptr_t)(rb + (((uint32_t)b & 3u) * 64u + lane) * 4) = v;
-        // mirror: a 2-dword read at slot 255 stays linear.  Lane 0 writes it when the block is the ring's first, the pad dword
-        // behind it otherwise (an address select, not a branch)
-        if (lane == 0) *(ls_l32)(uintptr_t)(rb + 1028u - (((uint32_t)b & 3u) == 0u ? mirror_sel : 0u)) = v;
+        const uint32_t slot = (uint32_t)b & (uint32_t)(LS_RB - 1);
+        *(ls_l32)(uintptr_t)(rb + (slot * 64u + lane) * 4) = v;
+        // mirror: a read of two or three dwords from the ring's last slots stays linear.  Lanes 0 and 1 write it when the block is
+        // the ring's first, the pad dwords behind it otherwise (an address select, not a branch)
+        if (lane < 2) *(ls_l32)(uintptr_t)(rb + LS_MIRROR + lane * 4 + (slot == 0u ? 0u : 8u)) = v;
     };
     uint32_t pf[LS_SPW];
 #pragma unroll
     for (int j = 0; j < LS_SPW; j++) {
-        store_blk(j, s_blk[j] + 1, load_blk(j, s_blk[j] + 1));
-        store_blk(j, s_blk[j], load_blk(j, s_blk[j]));
-        store_blk(j, s_blk[j] - 1, load_blk(j, s_blk[j] - 1));
-        pf[j] = load_blk(j, s_blk[j] - 2);                                  // enters the ring at the end of the first chunk
+#pragma unroll
+        for (int dd = -1; dd < LS_DEPTH; dd++) store_blk(j, s_blk[j] - dd, load_blk(j, s_blk[j] - dd));
+        s_pfb[j] = s_blk[j] - LS_DEPTH;
+        pf[j] = load_blk(j, s_pfb[j]);                                      // enters the ring at the end of the first chunk
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                                     // wave-private LDS: the writes above are in before the reads below
     // ---- chain state ---------------------------------------------------------------------------------------------
@@ -201,7 +214,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     const uint32_t cb = tbase - 2u * size;                                  // byte address of entry s = 2 * s + cb, s in [size, 2 * size)
     const uint32_t C = 31u - tl;
     auto window = [&](int32_t qq) -> uint32_t {
-        const uint32_t a = (__builtin_amdgcn_ubfe((uint32_t)qq, 5, 8) << 2) + ringb;
+        const uint32_t a = (__builtin_amdgcn_ubfe((uint32_t)qq, 5, LS_RBITS) << 2) + ringb;
         const uint32_t w0 = *(ls_l32)(uintptr_t)a, w1 = *(ls_l32)(uintptr_t)(a + 4);
         return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)qq);
     };
@@ -279,7 +292,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
         "v_add_u32_dpp %[pre], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         "v_add_u32 %[q], %[q], %[pre]\n\t"
 #define LS_ROUND_WINDOW \
-        "v_bfe_u32 %[at], %[q], 5, 8\n\t" \
+        "v_bfe_u32 %[at], %[q], 5, %[RW]\n\t" \
         "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
         "ds_read2_b32 v[62:63], %[at] offset1:1\n\t"
 #define LS_ROUND_HEAD \
@@ -293,8 +306,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
         "v_and_b32_dpp %[pre], %[m], %[mk1] quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
         "v_alignbit_b32 %[hi], %[hi], %[hi], %[pre]\n\t"
 #define LS_ROUND_TAIL LS_ROUND_LOOKUP LS_ROUND_ADVANCE LS_ROUND_WINDOW
-    // START / COUNT: stage byte offset of the first state and rounds of this piece (a whole chunk: 0, 64; tableLog 16 runs two halves
-    // with a ring refresh between them: at 16 bits a symbol a chunk may take 64 dwords off the 192 the ring has ahead)
+    // START / COUNT: stage byte offset of the first state and rounds of this piece (a whole chunk: 0, 64)
     // (a macro, not a lambda: clang does not capture through asm operands in a generic lambda)
 #define LS_CHUNK2(START_, COUNT_) do { \
         uint32_t e, c, m, hi, pre, at; \
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
                          ".endr\n\t" \
                          "s_waitcnt lgkmcnt(0)" \
                          : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
-                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_), [RW] "n"(LS_RBITS) \
                          : "memory", "vcc", "v62", "v63"); \
         else \
             asm volatile(".set ls_off, %[S]\n\t" \
@@ -322,8 +334,71 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
                          ".endr\n\t" \
                          "s_waitcnt lgkmcnt(0)" \
                          : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [m] "=&v"(m), [hi] "=&v"(hi), [pre] "=&v"(pre), [at] "=&v"(at) \
-                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_) \
+                         : [C] "v"(C), [mk1] "v"(mk1), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [S] "n"(START_), [R] "n"(COUNT_), [RW] "n"(LS_RBITS) \
                          : "memory", "v62", "v63"); \
+    } while (0)
+    // N = 4: one LDS round trip per round as well (tools/ubench_ls.hip, k_cand4: 136 cycles per round of four symbols; with every
+    // lane reading its own window behind the prefix sum -- two round trips -- it was 200).  The round's 64-bit window is read at
+    // its start position with the table look-ups: three ring dwords from the dword of q - 32 on (q is moved down by 32 for the
+    // chunk: the window's low half then starts at the tracked position) -> lo = bits [q-32, q), hi = bits [q, q+32) by two funnel
+    // shifts; a state's bits are the top nbBits of (hi:lo) << pre, pre = the bits of the states in front of it: v_lshlrev_b64.
+    // The prefix sum of m = -nbBits over the stream's four lanes runs in place on two v_add_u32_dpp, row_shr:1 and row_shr:2 without
+    // bound_ctrl: a stream's lanes open a DPP row, so lane 0 (lanes 0, 1) has no source and keeps its value; the chunk runs with
+    // EXEC = the states' lanes only.  The funnel shifts and a second v_sub for m fill the two wait states a DPP read of a fresh
+    // VGPR needs.
+    // The state a round ends with is staged in the tail, behind the window reads (the chunk's first one by the prologue).
+    // LDS queue at the top of a round, oldest first: entry, window (2), stage.
+#define LS_CHUNK4() do { \
+        uint32_t e, c, a, m, p, at, tot; \
+        const uint64_t ls_em = LS_SPW == 3 ? 0x0000000F000F000Full : LS_SPW == 2 ? 0x00000000000F000Full : 0xFull; \
+        q -= 32; \
+        asm volatile(".set ls_off, 8\n\t" \
+                     "s_mov_b64 exec, %[em]\n\t" \
+                     "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\t" \
+                     "ds_read_u16 %[e], %[at]\n\t" \
+                     "v_bfe_u32 %[at], %[q], 5, %[RW]\n\t" \
+                     "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
+                     "ds_read2_b32 v[60:61], %[at] offset1:1\n\t" \
+                     "ds_read_b32 v62, %[at] offset:8\n\t" \
+                     "ds_write_b16 %[stg], %[st]\n\t" \
+                     ".rept 32\n\t" \
+                     "s_waitcnt lgkmcnt(3)\n\t" \
+                     "v_ffbh_u32 %[c], %[e]\n\t" \
+                     "v_sub_u32 %[a], %[C], %[c]\n\t" \
+                     "s_waitcnt lgkmcnt(1)\n\t" \
+                     "v_alignbit_b32 v58, v61, v60, %[q]\n\t" \
+                     "v_add_u32_dpp %[a], %[a], %[a] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_alignbit_b32 v59, v62, v61, %[q]\n\t" \
+                     "v_sub_u32 %[m], %[C], %[c]\n\t" \
+                     "v_add_u32_dpp %[a], %[a], %[a] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_sub_u32 %[p], %[m], %[a]\n\t" \
+                     "v_lshlrev_b64 v[56:57], %[p], v[58:59]\n\t" \
+                     ".if %[ZBF]\n\t" \
+                     "v_alignbit_b32 %[p], %[e], v57, %[m]\n\t" \
+                     "v_cmp_eq_u32 vcc, 0, %[m]\n\t" \
+                     "v_cndmask_b32 %[st], %[p], %[e], vcc\n\t" \
+                     ".else\n\t" \
+                     "v_alignbit_b32 %[st], %[e], v57, %[m]\n\t" \
+                     ".endif\n\t" \
+                     "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\t" \
+                     "ds_read_u16 %[e], %[at]\n\t" \
+                     "v_mov_b32_dpp %[tot], %[a] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_add_u32 %[q], %[q], %[tot]\n\t" \
+                     "v_bfe_u32 %[at], %[q], 5, %[RW]\n\t" \
+                     "v_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t" \
+                     "ds_read2_b32 v[60:61], %[at] offset1:1\n\t" \
+                     "ds_read_b32 v62, %[at] offset:8\n\t" \
+                     ".if ls_off < 256\n\t" \
+                     "ds_write_b16 %[stg], %[st] offset:ls_off\n\t" \
+                     ".endif\n\t" \
+                     ".set ls_off, ls_off+8\n\t" \
+                     ".endr\n\t" \
+                     "s_waitcnt lgkmcnt(0)\n\t" \
+                     "s_mov_b64 exec, -1" \
+                     : [st] "+v"(st), [q] "+v"(q), [e] "=&v"(e), [c] "=&v"(c), [a] "=&v"(a), [m] "=&v"(m), [p] "=&v"(p), [at] "=&v"(at), [tot] "=&v"(tot) \
+                     : [C] "v"(C), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [RW] "n"(LS_RBITS), [ZBF] "n"(ZB ? 1 : 0), [em] "s"(ls_em) \
+                     : "memory", "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62"); \
+        q += 32; \
     } while (0)
     // ---- chunks of 128 symbols per stream ---------------------------------------------------------------------------
     constexpr uint32_t R = 128 / N;                                         // rounds per chunk
@@ -341,25 +416,8 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 #endif
     for (uint32_t ch = 0; ch < maxch; ch++) {
         if (ch == chunks) { sv_st = st; sv_q = q; }                         // (per lane) this stream is done: it runs on, harmlessly, on its own table
-        if (TL == 16) {
-            if (N == 2) LS_CHUNK2(0, 32);
-            else {
-#pragma unroll
-                for (uint32_t r = 0; r < R / 2; r++) round(r * N * 2u);
-            }
-#pragma unroll
-            for (int j = 0; j < LS_SPW; j++) store_blk(j, s_blk[j] - 2, pf[j]);            // mid-chunk ring refresh
-#pragma unroll
-            for (int j = 0; j < LS_SPW; j++) {
-                s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
-                pf[j] = load_blk(j, s_blk[j] - 2);
-            }
-            if (N == 2) LS_CHUNK2(128, 32);
-            else {
-#pragma unroll
-                for (uint32_t r = R / 2; r < R; r++) round(r * N * 2u);
-            }
-        } else if (N == 2) LS_CHUNK2(0, 64);
+        if (N == 2) LS_CHUNK2(0, 64);
+        else if (N == 4) LS_CHUNK4();
         else {
 #pragma unroll
             for (uint32_t r = 0; r < R; r++) round(r * N * 2u);
@@ -370,12 +428,13 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
         // have had a whole chunk to complete -- then the new loads, then the stores (vmcnt counts loads and stores together, in
         // order: a ring store behind a fresh global store would wait for that store's acknowledgement).
 #pragma unroll
-        for (int j = 0; j < LS_SPW; j++) store_blk(j, s_blk[j] - 2, pf[j]);
+        for (int j = 0; j < LS_SPW; j++) store_blk(j, s_pfb[j], pf[j]);
         LS_T(1);
 #pragma unroll
         for (int j = 0; j < LS_SPW; j++) {
-            s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
-            pf[j] = load_blk(j, s_blk[j] - 2);
+            s_blk[j] = ((int32_t)ls_rl((uint32_t)q, j * LS_LS) >> 5) >> 6;
+            s_pfb[j] = s_blk[j] - LS_DEPTH;
+            pf[j] = load_blk(j, s_pfb[j]);
         }
         LS_T(2);
         {
@@ -396,8 +455,9 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 #pragma unroll
         for (int j = 0; j < LS_SPW; j++) {
             if (!s_have[j]) continue;
-            const int32_t b = ((int32_t)ls_rl((uint32_t)q, j * N) >> 5) >> 6;
-            store_blk(j, b + 1, load_blk(j, b + 1)); store_blk(j, b, load_blk(j, b)); store_blk(j, b - 1, load_blk(j, b - 1));
+            const int32_t b = ((int32_t)ls_rl((uint32_t)q, j * LS_LS) >> 5) >> 6;
+#pragma unroll
+            for (int dd = -1; dd <= 2; dd++) store_blk(j, b - dd, load_blk(j, b - dd));   // (a tail of 127 symbols can take 64 dwords at tableLog 16)
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
@@ -405,12 +465,12 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     {
         uint32_t maxrem = 0;
 #pragma unroll
-        for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxrem = max(maxrem, ls_rl(rem, j * N));
+        for (int j = 0; j < LS_SPW; j++) if (s_have[j]) maxrem = max(maxrem, ls_rl(rem, j * LS_LS));
 #pragma unroll 1
         for (uint32_t r = 0; r * N < maxrem; r++) {
             const bool valid = r * N + k < rem;                             // fse2state.go:293-305 and siblings: the last states in lane order
             const uint32_t e = entry(st);
-            *(ls_l16)(uintptr_t)(stgb + r * N * 2u) = (uint16_t)st;
+            if (real) *(ls_l16)(uintptr_t)(stgb + r * N * 2u) = (uint16_t)st;
             const uint32_t nbr = (uint32_t)__builtin_clz(e) - C;
             const uint32_t nb = valid ? nbr : 0u;
             uint32_t pre, ntot; prefix(nb, pre, ntot);
@@ -423,7 +483,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 #pragma unroll
         for (int j = 0; j < LS_SPW; j++) {
             if (!s_have[j]) continue;
-            const uint32_t rj = ls_rl(rem, j * N), done = s_chunks[j] * 128u;
+            const uint32_t rj = ls_rl(rem, j * LS_LS), done = s_chunks[j] * 128u;
             const uint32_t s2 = *(ls_l32)(uintptr_t)((wv * LS_SPW + (uint32_t)j) * LS_STREAM_BYTES + LS_STAGE + lane * 4);
             const ls_gu16 o = (ls_gu16)(uintptr_t)s_out[j];
             if (2 * lane < rj) o[done + 2 * lane] = (uint16_t)s2;
@@ -431,7 +491,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
         }
     }
     // ---- results: one lane per stream -------------------------------------------------------------------------------
-    if (have && k == 0 && lane < LS_SPW * N) {
+    if (have && lane % LS_LS == 0 && lane < LS_SPW * LS_LS) {
         MicUnit &uo = units[list[slot0 + (int)g]];
         if (q + 32 - (int32_t)(8u * sb) < 0) uo.status = MICD_ERR_CORRUPT;  // bitreader.go:113-120: more bits taken than the stream holds
         else { uo.ntok = count; uo.walk_ok = 2; }                           // tok holds STATES: k_dec_translate turns them into symbols
@@ -443,12 +503,30 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 // the unit's symbol table (tableSymbol of each state, <= 16 KiB) sits in LDS, waves 1-3 stream the states through it in tiles
 // of 1536 (16 bytes in, eight LDS look-ups, 16 bytes out, in place) and leave each translated tile in LDS as well, where wave 0
 // follows the linked list of RLE headers through it (rledecompressu16.go:59-85: a header <= midCount is a run of one value, a
-// larger one a literal chunk) one tile behind, from a 64-token window and v_readlane -- no dependent HBM read per header.
-// Stop and error rules are those of the walkers in mic_decode.hip: on an error the segments are dropped and k_dec_pixels_wg
-// walks the stream itself and reports it.  Units that are not frames (bare FSE, WaveletV2, residual frames) are translated only.
+// larger one a literal chunk) one tile behind -- no dependent HBM read per header.
+// The walk is a serial chain (the next header's position is this one's value), but a self-synchronising one: a walk started at
+// a wrong token lands on a true header within a few steps and is the true walk from there.  Where headers are dense (run-heavy
+// streams: WaveletV2 coefficients, WSI planes) every lane therefore walks its 24 tokens of the tile from their first token on
+// its own, noting the positions it visits in a bit mask; the true walk then hops from lane to lane -- "is the position I
+// arrive at in your mask? then your exit is mine" (two v_readlane per 24 tokens instead of a loop trip per header; a lane whose
+// mask misses the arrival walks again from there) -- and the headers from the arrival bit on are the true ones.  Segment
+// records then leave from all lanes at once behind two DPP prefix sums (record index, first symbol).  Where headers are sparse
+// (long literal chunks: noisy frames) the plain header-to-header loop is the cheaper one; the previous tile's count picks.
+// Stop and error rules are those of the walkers in mic_decode.hip: on an error the segments are dropped and the consumer
+// (k_dec_pixels_wg, k_wv_expand) walks the stream itself and reports it.  Frames (mode 0) and length-prefixed RLE streams
+// (walk_mode 1: WaveletV2, rledecompressu16.go:21-30) are walked, other units are translated only.
 #define TR_THREADS 256                            // one walker wave + three translating waves: seven groups (walkers) per CU -- the walk is
                                                   // serial per unit, and on run-dense streams (WSI planes) it is what a unit waits for
 #define TR_TILE ((TR_THREADS - 64) * 8)
+#define TR_SEG (TR_TILE / 64)                     // tokens per walker lane
+#define TR_DENSE 6                                // headers in a tile from which on the next one is walked by all lanes
+static_assert(TR_SEG == 24 && TR_SEG * 64 == TR_TILE, "lane = position / 24 below is (position * 2731) >> 16");
+#define TR_DPP(x, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rmask), 0xF, false)
+__device__ __forceinline__ uint32_t tr_incl_add(uint32_t v) {             // wave-wide inclusive sum: row_shr 1/2/4/8, row_bcast 15 / 31
+    v += TR_DPP(v, 0x111, 0xF); v += TR_DPP(v, 0x112, 0xF); v += TR_DPP(v, 0x114, 0xF); v += TR_DPP(v, 0x118, 0xF);
+    v += TR_DPP(v, 0x142, 0xA); v += TR_DPP(v, 0x143, 0xC);
+    return v;
+}
 template <int TRTL>   // 13: tables up to 2^13 states (two groups per CU) | 16: up to 2^16 (128 KiB of LDS: one group per CU)
 __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
@@ -464,12 +542,16 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     }
     uint16_t *tok = u.tok;
     const bool frame = u.mode == 0 && u.seg != nullptr;
+    const bool prefixed = u.mode == 1 && u.walk_mode == 1 && u.seg != nullptr;   // mid, then the symbol count in two words, then headers
     // walker (wave 0; uniform values)
-    bool w_on = frame, w_err = false;
+    bool w_on = frame || prefixed, w_err = false, w_dense = false;
     uint32_t w_pos = 0, w_out = 0, w_nseg = 0, w_mid = 0;
-    const uint32_t w_symcap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u), w_segcap = u.seg_cap;
+    uint32_t w_cap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);   // frames: symbols the pixels can use; prefixed: the stream's own count
+    const uint32_t w_segcap = u.seg_cap;
     typedef __attribute__((address_space(1))) ls_v2 *seg_p;
     const seg_p w_seg = (seg_p)u.seg;
+    uint32_t *const w_tidx = prefixed ? u.flags : nullptr;                 // segment that holds symbol 8192 * k, for the expanding kernel's groups
+    if (prefixed && ntok < 3) { w_on = false; w_err = true; }
     __syncthreads();
     typedef uint32_t tr_v4 __attribute__((ext_vector_type(4)));
     const uint32_t smask = size - 1;                                        // a state carries its +size offset: index = state - size
@@ -492,37 +574,101 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
             }
         }
         __syncthreads();                                                    // tile `it` is in LDS; the walker is done with tile it - 1
-        if (wave == 0 && w_on) {
+        if (wave != 0 || !w_on || w_pos >= tile_end) continue;
+        if (w_pos == 0) {                                                   // token 0 fixes the run / literal split (rledecompressu16.go:21-25)
+            const int d0 = mic_len16(tile[0]);
+            if (d0 == 0) { w_on = false; w_err = true; continue; }
+            w_mid = (1u << (d0 - 1)) - 1; w_pos = 1;
+            if (prefixed) {
+                w_cap = ((uint32_t)tile[1] << 16) + tile[2]; w_pos = 3;
+                if (w_cap > u.sym_cap) { w_on = false; w_err = true; continue; }
+            }
+        }
+        const uint32_t nseg_in = w_nseg;
+        if (!w_dense) {
+            // ---- header to header, from a 64-token window and v_readlane ----
             while (w_on && w_pos < tile_end) {
                 const uint32_t rel = w_pos - base;                          // (>= 0: a header inside an earlier tile was taken there)
                 const uint32_t wv = (rel + lane < tile_end - base) ? (uint32_t)tile[rel + lane] : 0u;
                 uint32_t j = 0;
                 while (j < 64 && w_on && w_pos < tile_end) {
                     const uint32_t hd = ls_rl(wv, (int)j);
-                    if (w_pos == 0) {                                       // token 0 fixes the run / literal split
-                        const int d0 = mic_len16((uint16_t)hd);
-                        if (d0 == 0) { w_on = false; w_err = true; break; }
-                        w_mid = (1u << (d0 - 1)) - 1; w_pos = 1; j = 1;
-                        continue;
-                    }
-                    if (w_out >= w_symcap) { w_on = false; break; }
+                    if (w_out >= w_cap) { w_on = false; break; }
                     if (hd == 0 || w_nseg >= w_segcap) { w_on = false; w_err = true; break; }
-                    uint32_t adv;
+                    uint32_t adv, len;
                     if (hd <= w_mid) {
                         if (w_pos + 1 >= ntok) { w_on = false; w_err = true; break; }
                         if (lane == 0) { ls_v2 r; r.x = (w_pos + 1) | 0x80000000u; r.y = w_out; w_seg[w_nseg] = r; }
-                        w_nseg++; w_out += hd; adv = 2;
+                        len = hd; adv = 2;
                     } else {
                         if (lane == 0) { ls_v2 r; r.x = w_pos + 1; r.y = w_out; w_seg[w_nseg] = r; }
-                        w_nseg++; w_out += hd - w_mid; adv = 1 + (hd - w_mid);
+                        len = hd - w_mid; adv = 1 + len;
                     }
+                    if (w_tidx && ((w_out + len - 1) >> 13) != ((w_out - 1) >> 13) && lane == 0)
+                        for (uint32_t kk = (w_out + 8191u) >> 13; (kk << 13) < w_out + len; kk++) w_tidx[kk] = w_nseg;
+                    w_nseg++; w_out += len;
                     w_pos += adv; j += adv;                                 // j >= 64: the next header is outside the window
                 }
             }
+        } else {
+            // ---- all lanes: lane l walks tokens [24 l, 24 l + 24) of the tile from the first one on; the true walk enters at rel0 ----
+            const uint32_t tlen = tile_end - base, rel0 = w_pos - base;
+            const uint32_t s0 = lane * TR_SEG, s1 = min(s0 + TR_SEG, tlen);
+            uint32_t mask = 0, ex = 0;
+            auto lane_walk = [&](uint32_t p) {                              // mask: visited positions (bit = position - s0); ex: where the walk leaves
+                mask = 0;                                                   // the lane's tokens, ~0 when it met a zero header (an error if true)
+                while (p < s1) {
+                    const uint32_t h = tile[p];
+                    if (h == 0) { p = 0xFFFFFFFFu; break; }
+                    mask |= 1u << (p - s0);
+                    p += (h <= w_mid) ? 2u : 1u + h - w_mid;
+                }
+                ex = p;
+            };
+            { const uint32_t p0 = max(s0, rel0); if (p0 < s1) lane_walk(p0); }
+            uint32_t ent = 0xFFu;                                           // bit at which the true walk enters this lane's tokens (none: it jumps over them)
+            uint32_t cur = rel0;
+            while (cur < tlen) {
+                const uint32_t s = (cur * 2731u) >> 16, bit = cur - s * TR_SEG;
+                const uint32_t m = ls_rl(mask, (int)s);
+                if (!((m >> bit) & 1u)) { if (lane == s) lane_walk(cur); }  // not where that lane's own walk went: it walks again from here
+                if (lane == s) ent = bit;
+                cur = ls_rl(ex, (int)s);
+            }
+            const uint32_t tm = (ent != 0xFFu) ? (mask & (0xFFFFFFFFu << ent)) : 0u;   // this lane's true headers
+            uint32_t oc = 0;
+            for (uint32_t t = tm; t; t &= t - 1) { const uint32_t h = tile[s0 + (uint32_t)__builtin_ctz(t)]; oc += (h <= w_mid) ? h : h - w_mid; }
+            const uint32_t hc = (uint32_t)__popc(tm);
+            const uint32_t ihc = tr_incl_add(hc), ioc = tr_incl_add(oc);
+            const uint32_t tot_h = ls_rl(ihc, 63), tot_o = ls_rl(ioc, 63);
+            uint32_t idx = w_nseg + ihc - hc, o = w_out + ioc - oc, nval = 0;
+            bool bad = ent != 0xFFu && ex == 0xFFFFFFFFu && w_out + ioc < w_cap;   // the zero header is reached before the stream has its symbols
+            for (uint32_t t = tm; t; t &= t - 1) {
+                const uint32_t b = (uint32_t)__builtin_ctz(t), pos = base + s0 + b, h = tile[s0 + b];
+                const bool run = h <= w_mid;
+                const uint32_t len = run ? h : h - w_mid;
+                if (o < w_cap) {
+                    if (idx >= w_segcap || (run && pos + 1 >= ntok)) bad = true;
+                    else {
+                        ls_v2 r; r.x = (pos + 1) | (run ? 0x80000000u : 0u); r.y = o; w_seg[idx] = r;
+                        if (w_tidx && ((o + len - 1) >> 13) != ((o - 1) >> 13))
+                            for (uint32_t kk = (o + 8191u) >> 13; (kk << 13) < o + len; kk++) w_tidx[kk] = idx;
+                    }
+                    nval++;
+                }
+                idx++; o += len;
+            }
+            if (__ballot(bad)) { w_on = false; w_err = true; continue; }
+            if (w_out + tot_o >= w_cap) { w_nseg += ls_rl(tr_incl_add(nval), 63); w_on = false; }   // the stream has its symbols: headers behind that are not read
+            else w_nseg += tot_h;
+            w_out += tot_o;
+            w_pos = base + cur;
         }
+        w_dense = w_nseg - nseg_in >= TR_DENSE;
     }
     if (tid == 0) {
-        if (frame && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_symcap); u.walk_ok = 1; }
+        if (prefixed && !w_err && w_out < w_cap) w_err = true;             // tokens ran out before the announced count (Go: index panic)
+        if ((frame || prefixed) && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_cap); u.walk_ok = 1; }
         else u.walk_ok = 0;
     }
 }

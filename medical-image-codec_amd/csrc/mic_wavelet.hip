@@ -61,52 +61,82 @@ __device__ __forceinline__ int32_t wv_sample(Get c, int n, int k) {
     return c(n_low + i) + ((l + r) >> 1);
 }
 
+// One thread per PAIR of outputs (smooth i, detail i): both come from the same five inputs x[2i-2 .. 2i+2].  Grid: x = pairs (rows
+// pass) or columns (columns pass) in groups of 256, y = rows or pairs, z = frame of the batch; no division anywhere.
+// FROM_U16: level 0 reads the 16-bit pixels themselves (no widening pass); TO_U16: the last inverse pass stores 16-bit pixels.
+// rows of the r x c region: src -> dst, de-interleaved [low | high]   (waveletu16.go:170-182)
+template <bool FROM_U16>
+__global__ void __launch_bounds__(256) k_wv_fwd_rows(const void *__restrict__ src_, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
+    const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n_low) return;
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
+        for (int y = (int)blockIdx.y; y < r; y += (int)gridDim.y) {
+            const size_t ro = (size_t)f * fs + (size_t)y * stride;
+            int32_t sv, dv = 0;
+            if (FROM_U16) { const uint16_t *row = (const uint16_t *)src_ + ro; auto x = [&](int j) { return (int32_t)row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
+            else { const int32_t *row = (const int32_t *)src_ + ro; auto x = [&](int j) { return row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
+            dst[ro + i] = sv;
+            if (2 * i + 1 < c) dst[ro + n_low + i] = dv;
+        }
+}
+// columns of the r x c region   (waveletu16.go:183-208)
+__global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
+    const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (xcol >= c) return;
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
+        for (int i = (int)blockIdx.y; i < n_low; i += (int)gridDim.y) {
+            const int32_t *col = src + (size_t)f * fs + xcol;
+            auto x = [&](int j) { return col[(size_t)j * stride]; };
+            const int32_t sv = wv_s(x, r, i);
+            int32_t dv = 0;
+            if (2 * i + 1 < r) dv = wv_d(x, r, i);
+            int32_t *o = dst + (size_t)f * fs + xcol;
+            o[(size_t)i * stride] = sv;
+            if (2 * i + 1 < r) o[(size_t)(n_low + i) * stride] = dv;
+        }
+}
+// inverse: columns first, then rows   (waveletu16.go:213-257); a thread restores samples 2i and 2i+1 of its line
+template <typename Get>
+__device__ __forceinline__ void wv_pair(Get cf, int n, int i, int32_t &ev, int32_t &od) {
+    if (n < 2) { ev = cf(0); od = 0; return; }
+    const int n_low = (n + 1) / 2;
+    ev = wv_even(cf, n, i);
+    od = 0;
+    if (2 * i + 1 < n) { const int32_t rr = (2 * i + 2 < n) ? wv_even(cf, n, i + 1) : ev; od = cf(n_low + i) + ((ev + rr) >> 1); }
+}
+__global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
+    const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (xcol >= c) return;
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
+        for (int i = (int)blockIdx.y; i < n_low; i += (int)gridDim.y) {
+            const int32_t *col = src + (size_t)f * fs + xcol;
+            auto cf = [&](int j) { return col[(size_t)j * stride]; };
+            int32_t ev, od; wv_pair(cf, r, i, ev, od);
+            int32_t *o = dst + (size_t)f * fs + xcol;
+            o[(size_t)(2 * i) * stride] = ev;
+            if (2 * i + 1 < r) o[(size_t)(2 * i + 1) * stride] = od;
+        }
+}
+template <bool TO_U16>
+__global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *__restrict__ src, void *__restrict__ dst_, int r, int c, int stride, size_t fs, int nf) {
+    const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n_low) return;
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
+        for (int y = (int)blockIdx.y; y < r; y += (int)gridDim.y) {
+            const size_t ro = (size_t)f * fs + (size_t)y * stride;
+            const int32_t *row = src + ro;
+            auto cf = [&](int j) { return row[j]; };
+            int32_t ev, od; wv_pair(cf, c, i, ev, od);
+            if (TO_U16) { uint16_t *o = (uint16_t *)dst_ + ro; o[2 * i] = (uint16_t)ev; if (2 * i + 1 < c) o[2 * i + 1] = (uint16_t)od; }
+            else { int32_t *o = (int32_t *)dst_ + ro; o[2 * i] = ev; if (2 * i + 1 < c) o[2 * i + 1] = od; }
+        }
+}
+// (a frame the transform leaves untouched: zero levels)
 __global__ void __launch_bounds__(256) k_wv_load(const uint16_t *px, int32_t *a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = (int32_t)px[i];
 }
 __global__ void __launch_bounds__(256) k_wv_store(const int32_t *a, uint16_t *px, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) px[i] = (uint16_t)a[i];
-}
-// rows of the r x c region: src -> dst, de-interleaved [low | high]   (waveletu16.go:170-182)
-__global__ void __launch_bounds__(256) k_wv_fwd_rows(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
-    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
-    const size_t n = (size_t)r * c; const int n_low = (c + 1) / 2;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(t / c), k = (int)(t % c);
-        const int32_t *row = src + (size_t)y * stride;
-        auto x = [&](int j) { return row[j]; };
-        dst[(size_t)y * stride + k] = (k < n_low) ? wv_s(x, c, k) : wv_d(x, c, k - n_low);
-    }
-}
-// columns of the r x c region   (waveletu16.go:183-208)
-__global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
-    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
-    const size_t n = (size_t)r * c; const int n_low = (r + 1) / 2;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(t / c), xcol = (int)(t % c);
-        auto x = [&](int j) { return src[(size_t)j * stride + xcol]; };
-        dst[(size_t)k * stride + xcol] = (k < n_low) ? wv_s(x, r, k) : wv_d(x, r, k - n_low);
-    }
-}
-// inverse: columns first, then rows   (waveletu16.go:213-257)
-__global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
-    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
-    const size_t n = (size_t)r * c;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(t / c), xcol = (int)(t % c);
-        auto cf = [&](int j) { return src[(size_t)j * stride + xcol]; };
-        dst[(size_t)k * stride + xcol] = wv_sample(cf, r, k);
-    }
-}
-__global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *src, int32_t *dst, int r, int c, int stride, size_t fs) {
-    src += (size_t)blockIdx.y * fs; dst += (size_t)blockIdx.y * fs;                 // frame of the batch
-    const size_t n = (size_t)r * c;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(t / c), k = (int)(t % c);
-        const int32_t *row = src + (size_t)y * stride;
-        auto cf = [&](int j) { return row[j]; };
-        dst[(size_t)y * stride + k] = wv_sample(cf, c, k);
-    }
 }
 
 // collectSubbandOrder / scatterSubbandOrder as an index map (waveletfsecompressu16.go:202-282):
@@ -142,6 +172,7 @@ __device__ __forceinline__ uint32_t wv_wave_incl(uint32_t v, uint32_t lane) {
 // symbol stream into u.sym, its length into u.nsym and the RLE maxValue into u.max_value.
 __global__ void __launch_bounds__(WV_THREADS) k_wv_symbols(MicUnit *units, const int32_t *a, WvDims d) {
     MicUnit &u = units[blockIdx.x];
+    if (!u.wv_slow) return;                                               // k_wv_symbols_par did this frame
     a += (size_t)blockIdx.x * (size_t)d.rows * (size_t)d.cols;             // one group per frame of the batch
     __shared__ uint32_t s_scan[WV_WAVES], s_max[WV_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,9 +220,10 @@ __global__ void __launch_bounds__(WV_THREADS) k_wv_symbols(MicUnit *units, const
 // tokens -> symbols: RleDecompressU16.Init + Decompress (rledecompressu16.go:21-30, :87-97); header walk by
 // wave 0, expansion by all waves (as in mic_decode_px.hip), length taken from the two prefix words.
 // One work-group per unit; mode_filter >= 0 restricts the launch to units of that mode (MIC2 temporal residuals).
-__global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units, int mode_filter) {
+__global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units, int mode_filter, int only_slow) {
     MicUnit &u = units[blockIdx.x];
     if (mode_filter >= 0 && u.mode != (uint32_t)mode_filter) return;
+    if (only_slow && !u.wv_slow) return;                                  // k_wv_scatter did this frame
     if (u.status != MICD_OK) return;
     __shared__ uint32_t s_misc[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,7 +288,7 @@ __device__ __forceinline__ uint32_t wv_fn_compose(uint32_t g, uint32_t f) {     
 __global__ void __launch_bounds__(WV_THREADS) k_wv_coeffs(MicUnit *units, int32_t *a, WvDims d) {
     MicUnit &u = units[blockIdx.x];
     a += (size_t)blockIdx.x * (size_t)d.rows * (size_t)d.cols;
-    if (u.status != MICD_OK) return;
+    if (u.status != MICD_OK || !u.wv_slow) return;
     __shared__ uint32_t s_scan[WV_WAVES], s_fn[WV_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t m = u.nsym; const uint16_t *sym = u.sym;
@@ -301,12 +333,182 @@ __global__ void __launch_bounds__(WV_THREADS) k_wv_coeffs(MicUnit *units, int32_
     if (tid == 0 && (anybad || carry_n < n)) u.status = MICD_ERR_CORRUPT;          // fewer coefficients than pixels (Go: panic)
 }
 
+// ---- the usual case in parallel: frames whose coefficients all fit 16 bits (no 3-word escapes), many groups per frame -------------
+// Scan position p -> element offset, with the count of positions from p to the end of its subband row (they are consecutive
+// in memory): 32-bit arithmetic (a frame has at most 2^27 samples).
+__device__ __forceinline__ void wv_pos_row(const WvDims &d, uint32_t p, uint32_t &idx, uint32_t &left) {
+    const int L = d.levels;
+    const uint32_t cols = (uint32_t)d.cols;
+    {
+        const uint32_t w = (uint32_t)d.nc[L], sz = (uint32_t)d.nr[L] * w;
+        if (p < sz) { const uint32_t y = p / w, x = p - y * w; idx = y * cols + x; left = w - x; return; }
+        p -= sz;
+    }
+    for (int l = L; l >= 1; l--) {
+        const uint32_t nc = (uint32_t)d.nc[l], nr = (uint32_t)d.nr[l], hw = (uint32_t)d.nc[l - 1] - nc, lh = (uint32_t)d.nr[l - 1] - nr;
+        uint32_t sz = nr * hw;
+        if (p < sz) { const uint32_t y = p / hw, x = p - y * hw; idx = y * cols + nc + x; left = hw - x; return; }
+        p -= sz;
+        sz = lh * nc;
+        if (p < sz) { const uint32_t y = p / nc, x = p - y * nc; idx = (nr + y) * cols + x; left = nc - x; return; }
+        p -= sz;
+        sz = lh * hw;
+        if (p < sz) { const uint32_t y = p / hw, x = p - y * hw; idx = (nr + y) * cols + nc + x; left = hw - x; return; }
+        p -= sz;
+    }
+    idx = 0; left = 1;
+}
+#define WS_T 8192                                  // scan positions per group
+typedef uint32_t wv_v4 __attribute__((ext_vector_type(4)));
+typedef wv_v4 WvQ2 __attribute__((aligned(2)));
+typedef wv_v4 WvQ4 __attribute__((aligned(4)));
+// subband scan + zigzag, WS_T positions per group (grid: x = position tiles, y = frames).  A coefficient outside 16 bits sends the
+// frame to k_wv_symbols (wv_slow); the frame's largest symbol is gathered with an atomic max.
+__global__ void __launch_bounds__(1024) k_wv_symbols_par(MicUnit *units, const int32_t *a, WvDims d, int nf) {
+    const uint32_t n = (uint32_t)d.rows * (uint32_t)d.cols, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t i0 = blockIdx.x * WS_T + tid * 8;
+    for (int f = (int)blockIdx.y; f < nf; f += (int)gridDim.y) {
+        MicUnit &u = units[f];
+        const int32_t *af = a + (size_t)f * n;
+        uint32_t w8[4] = { 0u, 0u, 0u, 0u }, zmax = 0, idx = 0, left = 0; bool wide = false;
+        int32_t v8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (i0 < n) wv_pos_row(d, i0, idx, left);
+        if (i0 + 8 <= n && left >= 8) {                                    // the usual case: eight positions inside one subband row
+            const wv_v4 lo = *(const WvQ4 *)(af + idx), hi = *(const WvQ4 *)(af + idx + 4);
+            v8[0] = (int32_t)lo.x; v8[1] = (int32_t)lo.y; v8[2] = (int32_t)lo.z; v8[3] = (int32_t)lo.w;
+            v8[4] = (int32_t)hi.x; v8[5] = (int32_t)hi.y; v8[6] = (int32_t)hi.z; v8[7] = (int32_t)hi.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t p = i0 + (uint32_t)k;
+                if (p < n) {
+                    if (left == 0) wv_pos_row(d, p, idx, left);
+                    v8[k] = af[idx]; idx++; left--;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t v = v8[k];
+            if (v < -32767 || v > 32767) wide = true;
+            const uint32_t z = (uint32_t)((v >> 31) ^ (int32_t)((uint32_t)v << 1)) & 0xFFFF;   // zigzagEncode16, :538-541
+            zmax = max(zmax, z);
+            w8[k >> 1] |= z << (16 * (k & 1));
+        }
+        uint16_t *sym = u.sym;
+        if (i0 + 8 <= n) { wv_v4 v; v.x = w8[0]; v.y = w8[1]; v.z = w8[2]; v.w = w8[3]; *(wv_v4 *)(sym + i0) = v; }   // (256-byte aligned slab, i0 a multiple of 8)
+        else for (int k = 0; k < 8; k++) if (i0 + (uint32_t)k < n) sym[i0 + k] = (uint16_t)(w8[k >> 1] >> (16 * (k & 1)));
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, dd));
+        if (lane == 0 && zmax) atomicMax(&u.wv_zmax, zmax);
+        if (wide) u.wv_slow = 1;
+    }
+}
+// zzMax (:335-349) of the frames k_wv_symbols_par finished
+__global__ void __launch_bounds__(256) k_wv_symbols_fin(MicUnit *units, WvDims d, int nf) {
+    const int f = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (f >= nf) return;
+    MicUnit &u = units[f];
+    if (u.wv_slow) return;
+    const uint32_t m = u.wv_zmax;
+    int depth = m ? 32 - __clz(m) : 0;
+    if (depth < 1) depth = 1;
+    u.max_value = (uint16_t)((1u << depth) - 1);
+    u.nsym = (uint32_t)d.rows * (uint32_t)d.cols;
+    u.status = (u.nsym <= u.sym_cap) ? MICD_OK : MICD_ERR_CAPACITY;
+}
+
+// RLE expansion + zigzag decode + subband scatter in one pass, output-driven: a group owns WS_T consecutive scan positions, a
+// thread eight; the RLE segments k_dec_translate's walker left ({payload token | run flag, first symbol}, and in `flags` the
+// segment that holds every WS_T-th symbol) say where a position's symbol lies in the token stream (the fetch is
+// k_dec_pixels_wg's: segment table in LDS, gallop + bisection, one 16-byte load inside a literal chunk).  A frame with an escape
+// word (65535) in its symbols, fewer symbols than samples, or a stream the walker refused goes to k_wv_expand + k_wv_coeffs.
+__global__ void __launch_bounds__(1024) k_wv_scatter(MicUnit *units, int32_t *a, WvDims d) {
+    MicUnit &u = units[blockIdx.y];
+    if (u.status != MICD_OK) return;
+    const uint32_t n = (uint32_t)d.rows * (uint32_t)d.cols, tid = threadIdx.x;
+    if (u.walk_ok != 1 || u.nsym < n) { if (tid == 0) u.wv_slow = 1; return; }
+    __shared__ uint32_t s_segx[1024], s_segy[1024 + 1];
+    a += (size_t)blockIdx.y * n;
+    const uint32_t nseg = u.nseg, ntok = u.ntok;
+    const uint16_t *tok = u.tok;
+    const uint2 *seg = u.seg;
+    const uint32_t o0 = blockIdx.x * WS_T, tile_end = min(o0 + WS_T, n);
+    const uint32_t i0 = o0 + tid * 8, wend = min(i0 + 8, tile_end);
+    uint32_t w8[4] = { 0u, 0u, 0u, 0u }, bad = 0;
+    bool got = i0 >= tile_end;
+    for (uint32_t r0 = u.flags[blockIdx.x];; r0 += 1024 - 8) {            // table rounds overlap by 8 segments (8 symbols span at most 8)
+        __syncthreads();
+        const uint32_t si = r0 + tid;
+        uint2 sg = make_uint2(0u, 0xFFFFFFFFu);
+        if (si < nseg) sg = seg[si];
+        s_segx[tid] = sg.x; s_segy[tid] = sg.y;
+        if (tid == 0) { const uint32_t sj = r0 + 1024; s_segy[1024] = (sj < nseg) ? seg[sj].y : 0xFFFFFFFFu; }
+        __syncthreads();
+        const uint32_t cover_end = s_segy[1024];
+        if (!got && s_segy[0] <= i0 && wend <= cover_end) {
+            uint32_t j = 0, stp = 16;
+            while (j + stp <= 1024 && s_segy[j + stp] <= i0) { j += stp; stp <<= 1; }
+            for (stp >>= 1; stp; stp >>= 1) if (j + stp <= 1024 && s_segy[j + stp] <= i0) j += stp;
+            uint32_t start = s_segy[j], endj = s_segy[j + 1], sx = s_segx[j];
+            if (wend - i0 == 8 && i0 + 8 <= endj) {
+                const uint32_t xs = sx & 0x7FFFFFFFu;
+                if (sx >> 31) { const uint32_t v = (xs < ntok) ? tok[xs] : 0u; w8[0] = w8[1] = w8[2] = w8[3] = v | (v << 16); }
+                else {
+                    const uint32_t src = xs + (i0 - start);
+                    if (src + 8 <= ntok) { const wv_v4 v = *(const WvQ2 *)(tok + src); w8[0] = v.x; w8[1] = v.y; w8[2] = v.z; w8[3] = v.w; }
+                    else bad = 1;                                           // literal chunk past the end (Go: index panic)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t i = i0 + (uint32_t)k;
+                    if (i < wend) {
+                        while (i >= endj) { j++; start = s_segy[j]; endj = s_segy[j + 1]; sx = s_segx[j]; }
+                        const uint32_t xs = sx & 0x7FFFFFFFu;
+                        const uint32_t src = (sx >> 31) ? xs : xs + (i - start);
+                        if (src < ntok) w8[k >> 1] |= (uint32_t)tok[src] << (16 * (k & 1)); else bad = 1;
+                    }
+                }
+            }
+            got = true;
+        }
+        if (!(cover_end < tile_end)) break;
+    }
+    if (!got) bad = 1;
+    uint32_t idx = 0, left = 0;
+    int32_t v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t x = (w8[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (x == 65535u && i0 + (uint32_t)k < wend) bad = 1;               // an escape marker: positions and symbols part ways
+        v8[k] = (int32_t)((x >> 1) ^ (uint32_t)(-(int32_t)(x & 1)));       // zigzagDecode16, :543-546
+    }
+    if (bad) { u.wv_slow = 1; return; }
+    if (i0 >= wend) return;
+    wv_pos_row(d, i0, idx, left);
+    if (wend - i0 == 8 && left >= 8) {
+        wv_v4 lo, hi; lo.x = (uint32_t)v8[0]; lo.y = (uint32_t)v8[1]; lo.z = (uint32_t)v8[2]; lo.w = (uint32_t)v8[3];
+        hi.x = (uint32_t)v8[4]; hi.y = (uint32_t)v8[5]; hi.z = (uint32_t)v8[6]; hi.w = (uint32_t)v8[7];
+        *(WvQ4 *)(a + idx) = lo; *(WvQ4 *)(a + idx + 4) = hi;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + (uint32_t)k < wend) {
+                if (left == 0) wv_pos_row(d, i0 + (uint32_t)k, idx, left);
+                a[idx] = v8[k]; idx++; left--;
+            }
+        }
+    }
+}
+
 int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
+dim3 lift_grid(int x, int y, int nf) { return dim3((unsigned)((x + 255) / 256), (unsigned)std::max(1, std::min(y, 32768)), (unsigned)std::min(nf, 4096)); }
 
 }  // namespace
 
 void mic_launch_rle_expand(MicUnit *d_units, int n, hipStream_t stream, int mode_filter) {
-    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)n), dim3(WV_THREADS), 0, stream, d_units, mode_filter);
+    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)n), dim3(WV_THREADS), 0, stream, d_units, mode_filter, 0);
 }
 
 namespace {
@@ -326,12 +528,14 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     auto done = [&](int code) { return code; };
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
     s->timer.reset(s->stream);
-    s->timer.mark("k_wv_load+fwd_rows+fwd_cols");
-    hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
+    s->timer.mark("k_wv_fwd_rows+fwd_cols");
+    if (applied == 0) hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
     { int r = rows, c = cols;
       for (int l = 0; l < applied; l++) {
-          hipLaunchKernelGGL(k_wv_fwd_rows, dim3(grid_for((size_t)r * c), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, c, cols, n);
-          hipLaunchKernelGGL(k_wv_fwd_cols, dim3(grid_for((size_t)r * c), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n);
+          const dim3 gr = lift_grid((c + 1) / 2, r, nf), gc = lift_grid(c, (r + 1) / 2, nf);
+          if (l == 0) hipLaunchKernelGGL(k_wv_fwd_rows<true>, gr, dim3(256), 0, s->stream, (const void *)d_src, B, r, c, cols, n, nf);
+          else hipLaunchKernelGGL(k_wv_fwd_rows<false>, gr, dim3(256), 0, s->stream, (const void *)A, B, r, c, cols, n, nf);
+          hipLaunchKernelGGL(k_wv_fwd_cols, gc, dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n, nf);
           r = (r + 1) / 2; c = (c + 1) / 2;
       } }
     s->h_units.assign((size_t)nf, MicUnit{});
@@ -343,7 +547,13 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     if (hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     s->timer.mark("k_wv_symbols");
-    hipLaunchKernelGGL(k_wv_symbols, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, wv_dims(rows, cols, applied));
+    {
+        const WvDims d = wv_dims(rows, cols, applied);
+        hipLaunchKernelGGL(k_wv_symbols_par, dim3((unsigned)((n + WS_T - 1) / WS_T), (unsigned)std::min(nf, 65535)), dim3(1024), 0, s->stream,
+                           (MicUnit *)s->units.p, (const int32_t *)A, d, nf);
+        hipLaunchKernelGGL(k_wv_symbols_fin, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s->stream, (MicUnit *)s->units.p, d, nf);
+        hipLaunchKernelGGL(k_wv_symbols, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, d);   // frames with wide coefficients
+    }
     mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer);
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
     s->n_last = nf;
@@ -374,27 +584,29 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     s->h_units.assign((size_t)nf, MicUnit{});
     for (int i = 0; i < nf; i++) {
         MicUnit &u = s->h_units[(size_t)i];
-        u.comp_in = d_comp + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1;
+        u.comp_in = d_comp + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1; u.walk_mode = 1;
         s->fill_workspace(u, i);
     }
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
-    if (hipMemsetAsync(A, 0, n * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer, (int *)s->cls.p);
     const WvDims d = wv_dims(rows, cols, levels);
     if (s->timer.used) { s->timer.used--; s->timer.names.pop_back(); }   // (drop the chain's "end" mark: the wavelet kernels follow)
-    s->timer.mark("k_wv_expand");
-    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1);
-    s->timer.mark("k_wv_coeffs");
+    s->timer.mark("k_wv_scatter");
+    if (n >= ((size_t)65535 * WS_T) || nf > 65535) return done(MIC_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(k_wv_scatter, dim3((unsigned)((n + WS_T - 1) / WS_T), (unsigned)nf), dim3(1024), 0, s->stream, (MicUnit *)s->units.p, A, d);
+    s->timer.mark("k_wv_expand+coeffs (escape frames)");
+    hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1, 1);
     hipLaunchKernelGGL(k_wv_coeffs, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
-    s->timer.mark("k_wv_inv_cols+inv_rows+store");
+    s->timer.mark("k_wv_inv_cols+inv_rows");
+    if (levels == 0) hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];
-        hipLaunchKernelGGL(k_wv_inv_cols, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n);
-        hipLaunchKernelGGL(k_wv_inv_rows, dim3(grid_for((size_t)r * cc), (unsigned)nf), dim3(256), 0, s->stream, (const int32_t *)B, A, r, cc, cols, n);
+        hipLaunchKernelGGL(k_wv_inv_cols, lift_grid(cc, (r + 1) / 2, nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n, nf);
+        if (l == 0) hipLaunchKernelGGL(k_wv_inv_rows<true>, lift_grid((cc + 1) / 2, r, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)d_dst, r, cc, cols, n, nf);
+        else hipLaunchKernelGGL(k_wv_inv_rows<false>, lift_grid((cc + 1) / 2, r, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)A, r, cc, cols, n, nf);
     }
-    hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     s->timer.mark("end");
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
     s->n_last = nf;

@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(192) k_round(const uint16_t *tab, uint32_t *ou
 }
 
 // Bare chain (entry -> ffbh -> sub -> alignbit -> lshl_add -> entry) plus X extra DEPENDENT instructions of one kind in the chain:
-// K: 0 none | 1 v_alignbit_b32 | 2 v_and_b32_dpp quad_perm | 3 v_lshlrev_b32 | 4 s_waitcnt (satisfied) | 5 v_add_u32 | 6 v_mov_b32_dpp
+// K: 0 none | 1 v_alignbit_b32 | 2 v_and_b32_dpp quad_perm | 3 v_lshlrev_b32 | 4 s_waitcnt (satisfied) | 5 v_add_u32 | 6 v_mov_b32_dpp |
+//    7 v_mov + v_lshlrev_b64 + v_mov (the 64-bit shift between two moves)
 template <int K, int X>
 __global__ void __launch_bounds__(64) k_cost(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
     extern __shared__ uint32_t s_mem[];
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__(64) k_cost(const uint16_t *tab, uint32_t *out,
             ".elseif %[K] == 4\n\ts_waitcnt lgkmcnt(0)\n\t"
             ".elseif %[K] == 5\n\tv_add_u32 %[m], %[m], %[zero]\n\t"
             ".elseif %[K] == 6\n\tv_mov_b32_dpp %[m], %[m] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            ".elseif %[K] == 7\n\tv_mov_b32 v61, %[m]\n\tv_lshlrev_b64 v[62:63], %[zero], v[60:61]\n\tv_mov_b32 %[m], v63\n\t"
             ".endif\n\t"
             ".endr\n\t"
             "v_alignbit_b32 %[st], %[e], %[q], %[m]\n\t"
@@ -191,6 +193,89 @@ template <int W, int P> int cand(const char *name, const uint16_t *d_tab, uint32
     return 0;
 }
 
+// N = 4 in ONE LDS round trip: the round's 64-bit window (three ring dwords at the round's start position) is read with the table
+// look-ups; a state's bits are the top nbBits of window << (bits of the earlier states), a v_lshlrev_b64.  The in-quad prefix sum of
+// m = -nbBits runs in place on two v_add_u32_dpp with bank masks (lanes 1-3 add lane k-1, lanes 2-3 add lane k-2).
+// V: 0 as described | 1 without the 64-bit shift (two funnel shifts, compare, select: exact only for the first state's zero offset
+//    through a lane mask)
+template <int V>
+__global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
+    extern __shared__ uint32_t s_mem[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t g = lane / 4; if (g >= 3) g = 0;
+    const uint32_t k = lane & 3;
+    const uint32_t sbase = (wv * 3 + g) * STREAM_BYTES;
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t tb = ((wv * 3 + j) * STREAM_BYTES + TAB) >> 2;
+        for (uint32_t i = lane; i < 4096; i += 64) s_mem[tb + i] = ((const uint32_t *)tab)[i];
+        const uint32_t rb = ((wv * 3 + j) * STREAM_BYTES) >> 2;
+        for (uint32_t i = lane; i < 260; i += 64) s_mem[rb + i] = 0x9E3779B9u * (i + 1 + j);
+    }
+    __syncthreads();
+    const uint32_t cb = sbase + TAB - 2u * 8192u, C = 31u - 13u, ringb = sbase, stgb = sbase + STAGE + 2u * k;
+    const uint32_t K31 = (uint32_t)-31;
+    const uint64_t mk0 = 0x1111111111111111ull;
+    uint32_t st = 8192u + ((out[0] + 17u * lane) & 8191u), qm = 1u << 20;
+    uint32_t e, c, a, m, p, at, tot, xa, xb;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int ch = 0; ch < chunks; ch++) {
+        asm volatile(
+            ".set ls_off, 8\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            "v_bfe_u32 %[at], %[qm], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            "ds_read2_b32 v[60:61], %[at] offset1:1\n\tds_read_b32 v62, %[at] offset:8\n\t"
+            "ds_write_b16 %[stg], %[st]\n\t"
+            ".rept 32\n\t"
+            "s_waitcnt lgkmcnt(3)\n\t"
+            "v_ffbh_u32 %[c], %[e]\n\t"
+            "v_sub_u32 %[a], %[C], %[c]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbit_b32 v58, v61, v60, %[qm]\n\t"
+            "v_add_u32_dpp %[a], %[a], %[a] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xe\n\t"
+            "v_alignbit_b32 v59, v62, v61, %[qm]\n\t"
+            "v_sub_u32 %[m], %[C], %[c]\n\t"
+            "v_add_u32_dpp %[a], %[a], %[a] quad_perm:[0,0,0,1] row_mask:0xf bank_mask:0xc\n\t"
+            ".if %[V] == 0\n\t"
+            "v_sub_u32 %[p], %[m], %[a]\n\t"
+            "v_lshlrev_b64 v[56:57], %[p], v[58:59]\n\t"
+            "v_alignbit_b32 %[st], %[e], v57, %[m]\n\t"
+            ".else\n\t"
+            "v_sub_u32 %[p], %[a], %[m]\n\t"
+            "v_alignbit_b32 %[xa], v59, v58, %[p]\n\t"
+            "v_alignbit_b32 %[xb], v58, v58, %[p]\n\t"
+            "v_cmp_lt_i32 vcc, %[p], %[K31]\n\t"
+            "v_cndmask_b32 %[xa], %[xa], %[xb], vcc\n\t"
+            "v_cndmask_b32 %[xa], %[xa], v59, %[mk0]\n\t"
+            "v_alignbit_b32 %[st], %[e], %[xa], %[m]\n\t"
+            ".endif\n\t"
+            "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
+            "v_mov_b32_dpp %[tot], %[a] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32 %[qm], %[qm], %[tot]\n\t"
+            "v_bfe_u32 %[at], %[qm], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
+            "ds_read2_b32 v[60:61], %[at] offset1:1\n\tds_read_b32 v62, %[at] offset:8\n\t"
+            ".if ls_off < 256\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.endif\n\t"
+            ".set ls_off, ls_off+8\n\t"
+            ".endr\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [st] "+v"(st), [qm] "+v"(qm), [e] "=&v"(e), [c] "=&v"(c), [a] "=&v"(a), [m] "=&v"(m), [p] "=&v"(p), [at] "=&v"(at), [tot] "=&v"(tot),
+              [xa] "=&v"(xa), [xb] "=&v"(xb)
+            : [C] "v"(C), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [K31] "v"(K31), [mk0] "s"(mk0), [V] "n"(V)
+            : "memory", "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * 3 + wv] = t1 - t0;
+    if (st == 0xFFFFFFFFu) out[1] = st + qm;
+}
+template <int V> int cand4(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int chunks) {
+    CK(hipFuncSetAttribute((const void *)k_cand4<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * STREAM_BYTES));
+    hipLaunchKernelGGL((k_cand4<V>), dim3(1), dim3(192), 9 * STREAM_BYTES, 0, d_tab, d_out, chunks, d_cyc);
+    CK(hipDeviceSynchronize());
+    unsigned long long c[3];
+    CK(hipMemcpy(c, d_cyc, 24, hipMemcpyDeviceToHost));
+    printf("%-70s %6.1f cycles/round of FOUR symbols\n", name, (double)c[1] / ((double)chunks * 32.0));
+    return 0;
+}
+
 template <int V> int run(const char *name, const uint16_t *d_tab, uint32_t *d_out, unsigned long long *d_cyc, int blocks, int waves, int chunks) {
     CK(hipFuncSetAttribute((const void *)k_round<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * STREAM_BYTES));
     hipLaunchKernelGGL(k_round<V>, dim3(blocks), dim3(64 * waves), 9 * STREAM_BYTES, 0, d_tab, d_out, chunks, d_cyc);
@@ -219,6 +304,9 @@ int main() {
     cand<1, 1>("m-only round, two ds_read_b32, stage store in the head", d_tab, d_out, d_cyc, chunks);
     cand<0, 2>("... and v_and_dpp in front of the window wait", d_tab, d_out, d_cyc, chunks);
     cand<1, 2>("... the same with two ds_read_b32", d_tab, d_out, d_cyc, chunks);
+    cand4<0>("N = 4, one LDS round trip, v_lshlrev_b64", d_tab, d_out, d_cyc, chunks);
+    cand4<1>("N = 4, one LDS round trip, funnel shifts + selects", d_tab, d_out, d_cyc, chunks);
+    cost<7, 1>("v_mov, v_lshlrev_b64, v_mov", d_tab, d_out, d_cyc, chunks); cost<7, 4>("v_mov, v_lshlrev_b64, v_mov", d_tab, d_out, d_cyc, chunks);
     cost<0, 0>("(nothing)", d_tab, d_out, d_cyc, chunks);
     cost<1, 1>("v_alignbit_b32", d_tab, d_out, d_cyc, chunks); cost<1, 4>("v_alignbit_b32", d_tab, d_out, d_cyc, chunks);
     cost<2, 1>("v_and_b32_dpp", d_tab, d_out, d_cyc, chunks); cost<2, 4>("v_and_b32_dpp", d_tab, d_out, d_cyc, chunks);
