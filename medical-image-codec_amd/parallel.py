@@ -249,3 +249,151 @@ def session_codec(mic, sess, d_pixels, units: Sequence[Tuple[int, int, int, int,
         return out
 
     return encode, decode
+
+
+# ---- MIC3: a slide in bands of tile rows -------------------------------------------------------------------------------------
+# CompressWSI (wsicompress.go:83-145) codes every tile of every pyramid level on its own.  Level-0 tiles are three quarters of the
+# work and split into bands of tile rows with no shared data; a level-k tile covers 2^k tile rows of level 0, so a band that is a
+# multiple of tile_h * 2^K rows holds whole tiles of levels 0..K and the box filter (Downsample2xRGB, wsipyramid.go:10-32: 2x2
+# blocks, floor) never reaches across its edge.  Each rank therefore codes levels 0..K of its band as a slide of its own; the
+# rows of level K+1 (1 / 4^(K+1) of the pixels) are gathered on rank 0, which codes the few top levels, and the tile blobs are
+# gathered like any other unit.  The container is the reference's (wsiformat.go:99-285): 48-byte header, 20 bytes per level,
+# 16 bytes per tile, blobs in level order.
+def wsi_levels(width: int, height: int, tile_w: int, tile_h: int, levels_req: int = 0):
+    """autoLevelCount + computeLevels (wsiformat.go:244-285) with the pyramid's own stop (a level of zero rows or columns is
+    not built): [(level width, level height, tiles across, tiles down)]"""
+    n = levels_req
+    if n <= 0:
+        n, ww, hh = 1, width, height
+        while ww > tile_w or hh > tile_h:
+            ww //= 2; hh //= 2; n += 1
+            if ww <= 1 and hh <= 1:
+                break
+    out, ww, hh = [], width, height
+    for i in range(n):
+        if i and (ww == 0 or hh == 0):
+            break
+        out.append((ww, hh, (ww + tile_w - 1) // tile_w, (hh + tile_h - 1) // tile_h))
+        ww //= 2; hh //= 2
+    return out
+
+
+def wsi_band_plan(height: int, tile_h: int, num_levels: int, world: int):
+    """(K, [(y0, y1) per rank]): bands of tile_h * 2^K rows, K the largest level that still leaves every rank a band"""
+    k = num_levels - 1
+    while k > 0 and (height + (tile_h << k) - 1) // (tile_h << k) < world:
+        k -= 1
+    a = tile_h << k
+    nblocks = (height + a - 1) // a
+    bands = []
+    for r in range(world):
+        lo, hi = shard_range(nblocks, world, r)
+        bands.append((min(height, lo * a), min(height, hi * a)))
+    return k, bands
+
+
+def parse_mic3(buf: bytes):
+    """-> ([(lw, lh, ltx, lty, first tile)], tile lengths (int64 array, container order), offset of the first blob)"""
+    assert buf[:4] == b"MIC3"
+    nlev = int.from_bytes(buf[28:30], "little"); total = int.from_bytes(buf[32:40], "little")
+    lv = [tuple(int.from_bytes(buf[48 + 20 * i + 4 * k: 52 + 20 * i + 4 * k], "little") for k in range(5)) for i in range(nlev)]
+    tab = np.frombuffer(buf, dtype="<u8", count=2 * total, offset=48 + 20 * nlev).reshape(total, 2)
+    return lv, tab[:, 1].astype(np.int64), 48 + 20 * nlev + 16 * total
+
+
+def mic3_header(width: int, height: int, tile_w: int, tile_h: int, channels: int, bits: int, levels, sizes: Sequence[int]) -> bytes:
+    """WriteMIC3 header, level table and tile index (wsiformat.go:99-190) for tiles of the given sizes in container order"""
+    total = len(sizes)
+    hdr = bytearray(48 + 20 * len(levels) + 16 * total)
+    hdr[0:4] = b"MIC3"; hdr[4:8] = (1).to_bytes(4, "little")
+    for k, v in enumerate((width, height, tile_w, tile_h)):
+        hdr[8 + 4 * k: 12 + 4 * k] = int(v).to_bytes(4, "little")
+    hdr[24] = channels; hdr[26] = bits; hdr[27] = 0x01 | (0x02 if channels == 3 else 0)
+    hdr[28:30] = len(levels).to_bytes(2, "little"); hdr[32:40] = total.to_bytes(8, "little")
+    first = 0
+    for i, (lw, lh, ltx, lty) in enumerate(levels):
+        for k, v in enumerate((lw, lh, ltx, lty, first)):
+            hdr[48 + 20 * i + 4 * k: 52 + 20 * i + 4 * k] = int(v).to_bytes(4, "little")
+        first += ltx * lty
+    off, base = 0, 48 + 20 * len(levels)
+    for i, ln in enumerate(sizes):
+        hdr[base + 16 * i: base + 16 * i + 8] = off.to_bytes(8, "little")
+        hdr[base + 16 * i + 8: base + 16 * i + 16] = int(ln).to_bytes(8, "little")
+        off += int(ln)
+    return bytes(hdr)
+
+
+def downsample2x(img):
+    """Downsample2xRGB / Downsample2xGrey (wsipyramid.go:10-55) on a (rows, cols[, channels]) integer torch tensor"""
+    import torch
+    nh, nw = img.shape[0] // 2, img.shape[1] // 2
+    v = img[: 2 * nh, : 2 * nw].to(torch.int32)
+    return ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) // 4).to(img.dtype)
+
+
+def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int = 256, tile_h: int = 256, levels_req: int = 0,
+                      channels: int = 3, bits: int = 8, group=None) -> Optional[bytes]:
+    """CompressWSI over the ranks.  band: this rank's rows of the slide (wsi_band_plan's (y0, y1)) as a (rows, width[, channels])
+    tensor on the backend's device; encode_slide(image tensor, levels) -> the MIC3 file of that image as bytes (the injected
+    codec: a mic_hip session on a GPU, the oracle in the CPU tests).  Rank 0 returns the slide's MIC3 file, the others None."""
+    import torch
+    dist, world, rank = _dist(group)
+    levels = wsi_levels(width, height, tile_w, tile_h, levels_req)
+    L = len(levels)
+    K, bands = wsi_band_plan(height, tile_h, L, world)
+    y0, y1 = bands[rank]
+    assert band.shape[0] == y1 - y0 and band.shape[1] == width
+    dev = band.device
+    # 1. levels 0..K of the band, a slide of its own
+    nloc = [[((b1 - b0) >> k) for k in range(K + 1)] for b0, b1 in bands]                    # band rows per level (floor chain = shift: aligned bands)
+    tiles_of = [[((rows + tile_h - 1) // tile_h) * levels[k][2] if rows > 0 and k < L else 0 for k, rows in enumerate(nl)] for nl in nloc]
+    payload, sizes = torch.empty(0, dtype=torch.uint8, device=dev), torch.empty(0, dtype=torch.int64, device=dev)
+    if y1 > y0:
+        f = encode_slide(band, min(K + 1, L))
+        lv, sz, d0 = parse_mic3(f)
+        assert [t[2] * t[3] for t in lv] == [t for t in tiles_of[rank] if t], (lv, tiles_of[rank])
+        payload = torch.from_numpy(np.frombuffer(f, dtype=np.uint8, offset=d0).copy()).to(dev)
+        sizes = torch.from_numpy(sz).to(dev)
+    starts = np.concatenate([[0], np.cumsum([sum(t) for t in tiles_of])]).astype(np.int64)
+    allb, offs = _gather_by_shards(payload, sizes, [(int(starts[r]), int(starts[r + 1])) for r in range(world)], group)
+    # 2. the rows of level K + 1 go to rank 0, which codes the top of the pyramid
+    top_file = None
+    if L > K + 1:
+        t = band
+        for _ in range(K + 1):
+            t = downsample2x(t)
+        flat = t.contiguous().view(torch.uint8).reshape(-1)
+        row_bytes = levels[K + 1][0] * channels * (2 if bits == 16 else 1)
+        nrows = [(b1 - b0) >> (K + 1) for b0, b1 in bands]
+        topb, _ = _gather_by_shards(flat, torch.tensor([flat.numel()], dtype=torch.int64, device=dev), [(r, r + 1) for r in range(world)], group)
+        if rank == 0:
+            assert topb.numel() == sum(nrows) * row_bytes == levels[K + 1][1] * row_bytes, (topb.numel(), nrows, levels[K + 1])
+            shape = (levels[K + 1][1], levels[K + 1][0]) + ((channels,) if channels > 1 else ())
+            top_file = encode_slide(topb.view(band.dtype).reshape(shape), L - K - 1)
+    if rank != 0:
+        return None
+    # 3. the container: level by level, band by band
+    host = allb.cpu().numpy()
+    pieces, out_sizes = [], []
+    for k in range(min(K + 1, L)):
+        for r in range(world):
+            t0 = int(starts[r]) + sum(tiles_of[r][:k]); t1 = t0 + tiles_of[r][k]
+            pieces.append(host[int(offs[t0]): int(offs[t1])]); out_sizes.extend(np.diff(offs[t0: t1 + 1]).tolist())
+    if top_file is not None:
+        lv, sz, d0 = parse_mic3(top_file)
+        assert [(a, b, c, d) for a, b, c, d, _ in lv] == list(levels[K + 1:]), (lv, levels[K + 1:])
+        pieces.append(np.frombuffer(top_file, dtype=np.uint8, offset=d0)); out_sizes.extend(sz.tolist())
+    assert len(out_sizes) == sum(a[2] * a[3] for a in levels)
+    return mic3_header(width, height, tile_w, tile_h, channels, bits, levels, out_sizes) + b"".join(p.tobytes() for p in pieces)
+
+
+def session_wsi_codec(mic, sess, tile_w: int = 256, tile_h: int = 256):
+    """encode_slide for dist_compress_wsi on a GPU: the band (a device tensor) goes through the session's device-resident MIC3
+    encoder; the band's container is written on the host (assembly, outside the coding path)"""
+    def encode_slide(img, levels: int) -> bytes:
+        img = img.contiguous()
+        ch = img.shape[2] if img.dim() == 3 else 1
+        bits = 16 if img.element_size() == 2 else 8
+        sess.wsi_encode(img.data_ptr(), int(img.shape[1]), int(img.shape[0]), ch, bits, tile_w, tile_h, levels)
+        return sess.wsi_write()
+    return encode_slide

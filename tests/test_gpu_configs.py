@@ -217,5 +217,20 @@ def test_parallel_gather_on_rccl_world_size_1(mic, mico, synth, gpu_ready):
             rc, pw = mico.pics_compress(stack[f], 4095, 2, 2)
             assert rc == 0 and pics[f] == pw
         sess.close()
+        # MIC3 in bands: with one rank the band is the slide; a two-rank run's bands (tests/test_parallel_cpu.py: rows 0..1024 and
+        # 1024..1300 of this slide, levels 0..2) must come out of the session as they come out of the oracle
+        slide = synth.wsi_slide(520, 1300, seed=11, workers=1)
+        d_slide = torch.from_numpy(slide).cuda()
+        ws = mic.Session(64, 256 * 256, device=0)
+        enc_slide = par.session_wsi_codec(mic, ws)
+        rc, want3 = mico.wsi_compress(slide)
+        assert rc == 0 and par.dist_compress_wsi(enc_slide, d_slide, 520, 1300) == want3
+        for y0, y1 in ((0, 1024), (1024, 1300)):
+            rc, wb = mico.wsi_compress(np.ascontiguousarray(slide[y0:y1]), 256, 256, 3)
+            assert rc == 0 and enc_slide(d_slide[y0:y1], 3) == wb
+        top = par.downsample2x(par.downsample2x(par.downsample2x(d_slide)))
+        rc, wt = mico.wsi_compress(np.ascontiguousarray(top.cpu().numpy()), 256, 256, 1)
+        assert rc == 0 and enc_slide(top, 1) == wt
+        ws.close()
     finally:
         dist.destroy_process_group()

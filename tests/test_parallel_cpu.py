@@ -58,10 +58,30 @@ def _worker(rank, world, port, stack, q):
         strips = [(f, y0, min(h, y0 + sh)) for f in range(n) for y0 in range(0, h, sh)]
         enc_s, _ = _oracle_codec(mico, stack, 4095, strips)
         pics = par.dist_compress_pics_batch(enc_s, w, h, ns, n)                  # PICS batches: frames sharded, strips as units
+        # MIC3: the slide in bands of tile rows (levels 0..2 per band), the top of the pyramid (level 3) on rank 0
+        import torch
+        slide = synth_slide()
+        H, W = slide.shape[:2]
+        lv = par.wsi_levels(W, H, 256, 256, 0)
+        K, bands = par.wsi_band_plan(H, 256, len(lv), world)
+        assert len(lv) == 4 and K == 2 and bands == [(0, 1024), (1024, 1300)]
+
+        def encode_slide(img, levels):
+            rc, f = mico.wsi_compress(np.ascontiguousarray(img.numpy()), 256, 256, levels)
+            assert rc == 0
+            return f
+        y0, y1 = bands[rank]
+        mic3 = par.dist_compress_wsi(encode_slide, torch.from_numpy(slide[y0:y1].copy()), W, H)
         if rank == 0:
-            q.put((mic2, pics))
+            q.put((mic2, pics, mic3))
     finally:
         dist.destroy_process_group()
+
+
+def synth_slide():
+    """520 x 1300 RGB slide (ragged right and bottom edges), tiles of 256: four levels, bands of 1024 rows for two ranks"""
+    import importlib
+    return importlib.import_module("medical_image_codec_amd.synth").wsi_slide(520, 1300, seed=11, workers=1)
 
 
 def test_shard_range_is_a_partition(mic):
@@ -85,7 +105,7 @@ def test_two_rank_mic2_and_pics_assembly_match_single_process(mico, synth):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, stack, q)) for r in range(2)]
     for p in procs:
         p.start()
-    mic2, pics = q.get(timeout=120)
+    mic2, pics, mic3 = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -94,3 +114,5 @@ def test_two_rank_mic2_and_pics_assembly_match_single_process(mico, synth):
     for f in range(5):
         rc, pw = mico.pics_compress(stack[f], 4095, 3, 2)
         assert rc == 0 and pics[f] == pw
+    rc, want3 = mico.wsi_compress(synth_slide())
+    assert rc == 0 and mic3 == want3                                     # band by band + top of the pyramid = the slide coded in one piece

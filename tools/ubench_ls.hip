@@ -194,15 +194,17 @@ template <int W, int P> int cand(const char *name, const uint16_t *d_tab, uint32
 }
 
 // N = 4 in ONE LDS round trip: the round's 64-bit window (three ring dwords at the round's start position) is read with the table
-// look-ups; a state's bits are the top nbBits of window << (bits of the earlier states), a v_lshlrev_b64.  The in-quad prefix sum of
-// m = -nbBits runs in place on two v_add_u32_dpp with bank masks (lanes 1-3 add lane k-1, lanes 2-3 add lane k-2).
+// look-ups; a state's bits are the top nbBits of window << (bits of the earlier states), a v_lshlrev_b64.  The prefix sum of
+// m = -nbBits over a stream's four lanes runs in place on two v_add_u32_dpp (row_shr:1, row_shr:2, no bound_ctrl): a stream's lanes
+// open a DPP row of 16, so its first lane (first two) has no source and keeps its value; EXEC = the states' lanes.
+// (A DPP bank_mask selects groups of four CONSECUTIVE lanes, not lane % 4: it cannot do this inside a quad.)
 // V: 0 as described | 1 without the 64-bit shift (two funnel shifts, compare, select: exact only for the first state's zero offset
 //    through a lane mask)
 template <int V>
 __global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *out, int chunks, unsigned long long *cyc) {
     extern __shared__ uint32_t s_mem[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t g = lane / 4; if (g >= 3) g = 0;
+    uint32_t g = lane / 16; if (g >= 3) g = 0;
     const uint32_t k = lane & 3;
     const uint32_t sbase = (wv * 3 + g) * STREAM_BYTES;
     for (uint32_t j = 0; j < 3; j++) {
@@ -214,6 +216,7 @@ __global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *ou
     __syncthreads();
     const uint32_t cb = sbase + TAB - 2u * 8192u, C = 31u - 13u, ringb = sbase, stgb = sbase + STAGE + 2u * k;
     const uint32_t K31 = (uint32_t)-31;
+    const uint64_t em = 0x0000000F000F000Full;
     const uint64_t mk0 = 0x1111111111111111ull;
     uint32_t st = 8192u + ((out[0] + 17u * lane) & 8191u), qm = 1u << 20;
     uint32_t e, c, a, m, p, at, tot, xa, xb;
@@ -221,6 +224,7 @@ __global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *ou
     for (int ch = 0; ch < chunks; ch++) {
         asm volatile(
             ".set ls_off, 8\n\t"
+            "s_mov_b64 exec, %[em]\n\t"
             "v_lshl_add_u32 %[at], %[st], 1, %[cb]\n\tds_read_u16 %[e], %[at]\n\t"
             "v_bfe_u32 %[at], %[qm], 5, 8\n\tv_lshl_add_u32 %[at], %[at], 2, %[ringb]\n\t"
             "ds_read2_b32 v[60:61], %[at] offset1:1\n\tds_read_b32 v62, %[at] offset:8\n\t"
@@ -231,10 +235,10 @@ __global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *ou
             "v_sub_u32 %[a], %[C], %[c]\n\t"
             "s_waitcnt lgkmcnt(1)\n\t"
             "v_alignbit_b32 v58, v61, v60, %[qm]\n\t"
-            "v_add_u32_dpp %[a], %[a], %[a] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xe\n\t"
+            "v_add_u32_dpp %[a], %[a], %[a] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
             "v_alignbit_b32 v59, v62, v61, %[qm]\n\t"
             "v_sub_u32 %[m], %[C], %[c]\n\t"
-            "v_add_u32_dpp %[a], %[a], %[a] quad_perm:[0,0,0,1] row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_u32_dpp %[a], %[a], %[a] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
             ".if %[V] == 0\n\t"
             "v_sub_u32 %[p], %[m], %[a]\n\t"
             "v_lshlrev_b64 v[56:57], %[p], v[58:59]\n\t"
@@ -256,10 +260,11 @@ __global__ void __launch_bounds__(192) k_cand4(const uint16_t *tab, uint32_t *ou
             ".if ls_off < 256\n\tds_write_b16 %[stg], %[st] offset:ls_off\n\t.endif\n\t"
             ".set ls_off, ls_off+8\n\t"
             ".endr\n\t"
-            "s_waitcnt lgkmcnt(0)"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, -1"
             : [st] "+v"(st), [qm] "+v"(qm), [e] "=&v"(e), [c] "=&v"(c), [a] "=&v"(a), [m] "=&v"(m), [p] "=&v"(p), [at] "=&v"(at), [tot] "=&v"(tot),
               [xa] "=&v"(xa), [xb] "=&v"(xb)
-            : [C] "v"(C), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [K31] "v"(K31), [mk0] "s"(mk0), [V] "n"(V)
+            : [C] "v"(C), [cb] "v"(cb), [ringb] "v"(ringb), [stg] "v"(stgb), [K31] "v"(K31), [mk0] "s"(mk0), [em] "s"(em), [V] "n"(V)
             : "memory", "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
