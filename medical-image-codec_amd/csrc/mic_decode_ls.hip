@@ -513,8 +513,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
 // records then leave from all lanes at once behind two DPP prefix sums (record index, first symbol).  Where headers are sparse
 // (long literal chunks: noisy frames) the plain header-to-header loop is the cheaper one; the previous tile's count picks.
 // Stop and error rules are those of the walkers in mic_decode.hip: on an error the segments are dropped and the consumer
-// (k_dec_pixels_wg, k_wv_expand) walks the stream itself and reports it.  Frames (mode 0) and length-prefixed RLE streams
-// (walk_mode 1: WaveletV2, rledecompressu16.go:21-30) are walked, other units are translated only.
+// (k_dec_pixels_wg) walks the stream itself and reports it.  Frames (mode 0) are walked, other units are translated only.
 #define TR_THREADS 256                            // one walker wave + three translating waves: seven groups (walkers) per CU -- the walk is
                                                   // serial per unit, and on run-dense streams (WSI planes) it is what a unit waits for
 #define TR_TILE ((TR_THREADS - 64) * 8)
@@ -542,16 +541,16 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     }
     uint16_t *tok = u.tok;
     const bool frame = u.mode == 0 && u.seg != nullptr;
-    const bool prefixed = u.mode == 1 && u.walk_mode == 1 && u.seg != nullptr;   // mid, then the symbol count in two words, then headers
+    // (a length-prefixed RLE stream, walk_mode 1 -- a whole WaveletV2 frame -- is one unit of millions of tokens: walking it here would
+    //  be one wave's work per frame; it is marked walk_ok = 3 and walked in parts by k_rle_walk_parts, mic_wavelet.hip)
+    const bool prefixed = u.mode == 1 && u.walk_mode == 1 && u.seg != nullptr;
     // walker (wave 0; uniform values)
-    bool w_on = frame || prefixed, w_err = false, w_dense = false;
+    bool w_on = frame, w_err = false, w_dense = false;
     uint32_t w_pos = 0, w_out = 0, w_nseg = 0, w_mid = 0;
-    uint32_t w_cap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);   // frames: symbols the pixels can use; prefixed: the stream's own count
+    const uint32_t w_cap = min(u.sym_cap, 2u * (uint32_t)u.w * (uint32_t)u.h + 2u);   // symbols the pixels can use
     const uint32_t w_segcap = u.seg_cap;
     typedef __attribute__((address_space(1))) ls_v2 *seg_p;
     const seg_p w_seg = (seg_p)u.seg;
-    uint32_t *const w_tidx = prefixed ? u.flags : nullptr;                 // segment that holds symbol 8192 * k, for the expanding kernel's groups
-    if (prefixed && ntok < 3) { w_on = false; w_err = true; }
     __syncthreads();
     typedef uint32_t tr_v4 __attribute__((ext_vector_type(4)));
     const uint32_t smask = size - 1;                                        // a state carries its +size offset: index = state - size
@@ -579,10 +578,6 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
             const int d0 = mic_len16(tile[0]);
             if (d0 == 0) { w_on = false; w_err = true; continue; }
             w_mid = (1u << (d0 - 1)) - 1; w_pos = 1;
-            if (prefixed) {
-                w_cap = ((uint32_t)tile[1] << 16) + tile[2]; w_pos = 3;
-                if (w_cap > u.sym_cap) { w_on = false; w_err = true; continue; }
-            }
         }
         const uint32_t nseg_in = w_nseg;
         if (!w_dense) {
@@ -604,8 +599,6 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
                         if (lane == 0) { ls_v2 r; r.x = w_pos + 1; r.y = w_out; w_seg[w_nseg] = r; }
                         len = hd - w_mid; adv = 1 + len;
                     }
-                    if (w_tidx && ((w_out + len - 1) >> 13) != ((w_out - 1) >> 13) && lane == 0)
-                        for (uint32_t kk = (w_out + 8191u) >> 13; (kk << 13) < w_out + len; kk++) w_tidx[kk] = w_nseg;
                     w_nseg++; w_out += len;
                     w_pos += adv; j += adv;                                 // j >= 64: the next header is outside the window
                 }
@@ -651,8 +644,6 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
                     if (idx >= w_segcap || (run && pos + 1 >= ntok)) bad = true;
                     else {
                         ls_v2 r; r.x = (pos + 1) | (run ? 0x80000000u : 0u); r.y = o; w_seg[idx] = r;
-                        if (w_tidx && ((o + len - 1) >> 13) != ((o - 1) >> 13))
-                            for (uint32_t kk = (o + 8191u) >> 13; (kk << 13) < o + len; kk++) w_tidx[kk] = idx;
                     }
                     nval++;
                 }
@@ -667,9 +658,8 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
         w_dense = w_nseg - nseg_in >= TR_DENSE;
     }
     if (tid == 0) {
-        if (prefixed && !w_err && w_out < w_cap) w_err = true;             // tokens ran out before the announced count (Go: index panic)
-        if ((frame || prefixed) && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_cap); u.walk_ok = 1; }
-        else u.walk_ok = 0;
+        if (frame && !w_err) { u.nseg = w_nseg; u.nsym = min(w_out, w_cap); u.walk_ok = 1; }
+        else u.walk_ok = prefixed ? 3u : 0u;
     }
 }
 

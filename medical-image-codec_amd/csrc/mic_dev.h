@@ -57,8 +57,9 @@ struct MicUnit {
     uint32_t  nsym;
     uint32_t  walk_ok;        // decode: seg/nseg/nsym already produced by the tANS kernel's header walker
     uint32_t  dec_thr;        // decode: delta threshold (1 << (depth-1)) - 1 of the stream's own max value
-    uint32_t  walk_mode;      // decode, mode 1 units: 1 = the symbols are a length-prefixed RLE stream (WaveletV2): k_dec_translate walks its
-                              // headers too (seg / nseg / nsym, walk_ok = 1) and leaves in `flags` the segment that holds every 8192nd symbol
+    uint32_t  walk_mode;      // decode, mode 1 units: 1 = the symbols are a length-prefixed RLE stream (WaveletV2): k_dec_translate marks it
+                              // walk_ok = 3 and k_rle_walk_* (mic_wavelet.hip) walk its headers in parts: seg / nseg / nsym, walk_ok = 1,
+                              // and in `flags` the segment that holds every 8192nd symbol
     uint32_t  wv_slow;        // WaveletV2: this frame takes the one-group kernels (escape words in its stream, or a stream the walker refused)
     uint32_t  wv_zmax;        // WaveletV2 encode: largest zigzag symbol of the frame
     // ---- results -----------------------------------------------------------------

@@ -358,7 +358,7 @@ __device__ __forceinline__ void wv_pos_row(const WvDims &d, uint32_t p, uint32_t
     }
     idx = 0; left = 1;
 }
-#define WS_T 8192                                  // scan positions per group
+#define WS_T 8192                                  // scan positions per group (a power of two: >> 13 below)
 typedef uint32_t wv_v4 __attribute__((ext_vector_type(4)));
 typedef wv_v4 WvQ2 __attribute__((aligned(2)));
 typedef wv_v4 WvQ4 __attribute__((aligned(4)));
@@ -416,6 +416,167 @@ __global__ void __launch_bounds__(256) k_wv_symbols_fin(MicUnit *units, WvDims d
     u.max_value = (uint16_t)((1u << depth) - 1);
     u.nsym = (uint32_t)d.rows * (uint32_t)d.cols;
     u.status = (u.nsym <= u.sym_cap) ? MICD_OK : MICD_ERR_CAPACITY;
+}
+
+// ---- the RLE header walk of a whole frame, in parts -----------------------------------------------------------------------------
+// A WaveletV2 frame is ONE token stream of millions of tokens whose headers form a linked list (rledecompressu16.go:59-85: the
+// next header's position is this one's value), and a walk costs a wave some hundreds of cycles per header whatever else the GPU
+// does.  But the list is self-synchronising: a walk started at a token that is no header lands on a true one within a few steps
+// and is the true walk from there.  So the stream is cut into WP_PARTS parts, a wave per part walks from the part's first token
+// (part 0: from the first header) and leaves its records {payload token | run flag, first symbol RELATIVE to the part} in a
+// region of its own; k_rle_walk_fix then hops from part to part -- the true walk enters a part at the exit of the part before,
+// that position is looked up among the part's first 64 records (if it is not there the frame goes to k_wv_expand) -- and
+// k_rle_walk_compact moves the true records to the front of `seg` with their absolute symbol positions, filling `flags` with
+// the segment that holds every WS_T-th symbol.  Stop and error rules are k_wv_expand's.
+#define WP_PARTS 64
+#define WP_MINLEN 4096u
+#define WP_EXTRA 1024u                             // true headers a part may hold in front of the point where its own walk joins the true one
+// per part, in the unit's cumul[] slab (free after the tables)
+struct WpPart { uint32_t start, exit, nrec, out_total, err, first, base_seg, out_delta, nextra, extra_base, pad0, pad1; };
+__device__ __forceinline__ uint32_t wp_part_len(uint32_t ntok) { return max(WP_MINLEN, (((ntok + WP_PARTS - 1) / WP_PARTS) + 63u) & ~63u); }
+__device__ __forceinline__ uint32_t wp_stride(uint32_t L) { return L / 2 + 1 + WP_EXTRA + 1; }     // records of a part: its own walk's, then the extras (+ an end mark)
+__device__ __forceinline__ bool wp_fits(const MicUnit &u, uint32_t L) {        // temporary records in the upper half of seg, final ones in the lower
+    const uint32_t nparts = (u.ntok + L - 1) / L;
+    return u.seg != nullptr && (uint64_t)nparts * wp_stride(L) <= u.seg_cap / 2 && u.ntok / 2 + 2 <= u.seg_cap / 2;
+}
+__global__ void __launch_bounds__(64) k_rle_walk_parts(MicUnit *units) {
+    MicUnit &u = units[blockIdx.y];
+    if (u.status != MICD_OK || u.walk_mode != 1 || u.walk_ok != 3) return;
+    const uint32_t ntok = u.ntok, p = blockIdx.x, lane = threadIdx.x;
+    if (ntok < 3) return;
+    const uint16_t *tok = u.tok;
+    const uint32_t L = wp_part_len(ntok), lo = p * L;
+    if (lo >= ntok || !wp_fits(u, L)) return;
+    const uint32_t hi = min(lo + L, ntok);
+    const int d0 = mic_len16(tok[0]);
+    if (d0 == 0) return;
+    const uint32_t mid = (1u << (d0 - 1)) - 1;
+    uint2 *rec = u.seg + u.seg_cap / 2 + (size_t)p * wp_stride(L);
+    uint32_t pos = p ? lo : 3u, out = 0, nrec = 0, err = 0;
+    const uint32_t start = pos;
+    while (pos < hi && !err) {
+        const uint32_t w = (pos + lane < ntok) ? tok[pos + lane] : 0u;
+        uint32_t j = 0;
+        while (j < 64 && pos + j < hi) {
+            const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)j);
+            if (h == 0) {
+                // an encoder never writes a zero count.  The first part's walk is the true one: an error; any other part's walk started at
+                // some token and has just proved itself wrong (zero symbols are common in literal chunks): it starts over behind the zero
+                if (p == 0) { err = 1; break; }
+                nrec = 0; out = 0; j += 1;
+                continue;
+            }
+            if (h <= mid) {
+                if (pos + j + 1 >= ntok) { if (p == 0) err = 1; else { nrec = 0; out = 0; j = 64; pos = hi; } break; }
+                if (lane == 0) rec[nrec] = make_uint2((pos + j + 1) | 0x80000000u, out);
+                nrec++; out += h; j += 2;
+            } else {
+                if (lane == 0) rec[nrec] = make_uint2(pos + j + 1, out);
+                nrec++; out += h - mid; j += 1 + (h - mid);
+            }
+        }
+        pos += j;
+    }
+    if (lane == 0) {
+        WpPart &s = ((WpPart *)u.cumul)[p];
+        s.start = start; s.exit = err ? 0xFFFFFFFFu : pos; s.nrec = nrec; s.out_total = out; s.err = err; s.first = 0xFFFFFFFFu; s.nextra = 0;
+    }
+}
+// One wave per unit: the true walk from part to part.  In a part it first takes the true headers the part's own walk has not got
+// (that walk started at a token that need not be a header; it joins the true one after a few of them) -- read from a 64-token
+// window, noted as "extras" with their absolute symbol positions -- until it stands on a position the part has a record of.
+__global__ void __launch_bounds__(64) k_rle_walk_fix(MicUnit *units) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.walk_mode != 1 || u.walk_ok != 3) return;
+    const uint32_t ntok = u.ntok, lane = threadIdx.x;
+    const uint32_t L = wp_part_len(max(ntok, 1u));
+    const uint16_t *tok = u.tok;
+    bool ok = ntok >= 3 && wp_fits(u, L) && mic_len16(tok[0]) != 0;
+    const uint32_t cap = ok ? ((uint32_t)tok[1] << 16) + tok[2] : 0u;
+    const uint32_t mid = ok ? (1u << (mic_len16(tok[0]) - 1)) - 1 : 0u;
+    if (cap > u.sym_cap) ok = false;
+    WpPart *S = (WpPart *)u.cumul;
+    uint32_t e = 3, N = 0, O = 0;                                           // the next true header, records and symbols in front of it
+    uint32_t wbase = 0xFFFFFFFFu, wtok = 0;                                 // token window [wbase, wbase + 64)
+    while (ok && e < ntok && O < cap) {
+        const uint32_t q = e / L, hi = min((q + 1) * L, ntok);
+        const WpPart s = S[q];
+        uint2 *rec = u.seg + u.seg_cap / 2 + (size_t)q * wp_stride(L);
+        uint2 *extra = rec + (L / 2 + 1);
+        uint32_t blk = 0, nx = 0, first = s.nrec;
+        const uint32_t N0 = N;
+        uint2 r = (lane < s.nrec) ? rec[lane] : make_uint2(0xFFFFFFFFu, 0u);
+        bool synced = false;
+        uint32_t r0 = 0;
+        while (e < hi && O < cap) {
+            // first record of the part at or behind e
+            uint64_t m;
+            while (!(m = __ballot((r.x & 0x7FFFFFFFu) >= e + 1)) && (blk + 1) * 64 < s.nrec) {
+                blk++;
+                r = (blk * 64 + lane < s.nrec) ? rec[blk * 64 + lane] : make_uint2(0xFFFFFFFFu, 0u);
+            }
+            if (m) {
+                const int i = (int)__builtin_ctzll(m);
+                const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)r.x, i) & 0x7FFFFFFFu;
+                if (px == e + 1 && blk * 64 + (uint32_t)i < s.nrec) {       // the part's own walk stands here too: the rest of it is true
+                    first = blk * 64 + (uint32_t)i;
+                    r0 = (uint32_t)__builtin_amdgcn_readlane((int)r.y, i);
+                    synced = true;
+                    break;
+                }
+            }
+            // a true header the part has no record of
+            if (e - wbase >= 64u) { wbase = e; wtok = (e + lane < ntok) ? tok[e + lane] : 0u; }
+            const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)wtok, (int)(e - wbase));
+            if (h == 0 || nx >= WP_EXTRA) { ok = false; break; }                // (a zero count: corrupt; too many: the one-group kernels take the frame)
+            const bool run = h <= mid;
+            if (run && e + 1 >= ntok) { ok = false; break; }
+            const uint32_t len = run ? h : h - mid;
+            if (lane == 0) extra[nx] = make_uint2((e + 1) | (run ? 0x80000000u : 0u), O);
+            nx++; O += len; e += run ? 2u : 1u + len;
+        }
+        if (!ok) break;
+        if (lane == 0) {
+            extra[nx] = make_uint2(0u, O);                                  // end mark: the symbol position behind the last extra
+            S[q].first = first; S[q].nextra = nx; S[q].extra_base = N0; S[q].base_seg = N0 + nx; S[q].out_delta = O - r0;
+        }
+        N = N0 + nx;
+        if (!synced) continue;                                              // the true walk left the part on its own (or the stream has its symbols)
+        N += s.nrec - first; O += s.out_total - r0;
+        if (s.err) { if (O < cap) ok = false; break; }                      // the zero header is reached before the stream has its symbols
+        e = s.exit;
+    }
+    if (ok && O < cap) ok = false;                                          // tokens ran out (Go: index panic)
+    if (lane == 0) {
+        if (ok) { u.nseg = N; u.nsym = cap; u.walk_ok = 1; }
+        else u.walk_ok = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_rle_walk_compact(MicUnit *units) {
+    MicUnit &u = units[blockIdx.y];
+    if (u.status != MICD_OK || u.walk_mode != 1 || u.walk_ok != 1) return;
+    const uint32_t L = wp_part_len(u.ntok), q = blockIdx.x;
+    if (q * L >= u.ntok) return;
+    const WpPart s = ((const WpPart *)u.cumul)[q];
+    if (s.first == 0xFFFFFFFFu) return;                                     // the true walk jumps over this part (or ends before it)
+    const uint2 *rec = u.seg + u.seg_cap / 2 + (size_t)q * wp_stride(L);
+    const uint2 *extra = rec + (L / 2 + 1);
+    uint32_t *tidx = u.flags;
+    const uint32_t nsym = u.nsym;
+    auto put = [&](uint32_t idx, uint32_t x, uint32_t o, uint32_t len) {
+        u.seg[idx] = make_uint2(x, o);
+        if (((o + len - 1) >> 13) != ((o - 1) >> 13))
+            for (uint32_t kk = (o + (WS_T - 1)) >> 13; (kk << 13) < o + len && (kk << 13) < nsym; kk++) tidx[kk] = idx;
+    };
+    for (uint32_t r = threadIdx.x; r < s.nextra; r += 256) {                // (absolute symbol positions; the end mark carries the position behind the last)
+        const uint2 v = extra[r];
+        put(s.extra_base + r, v.x, v.y, extra[r + 1].y - v.y);
+    }
+    for (uint32_t r = s.first + threadIdx.x; r < s.nrec; r += 256) {
+        const uint2 v = rec[r];
+        const uint32_t nxt = (r + 1 < s.nrec) ? rec[r + 1].y : s.out_total;
+        put(s.base_seg + (r - s.first), v.x, v.y + s.out_delta, nxt - v.y);
+    }
 }
 
 // RLE expansion + zigzag decode + subband scatter in one pass, output-driven: a group owns WS_T consecutive scan positions, a
@@ -593,8 +754,12 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer, (int *)s->cls.p);
     const WvDims d = wv_dims(rows, cols, levels);
     if (s->timer.used) { s->timer.used--; s->timer.names.pop_back(); }   // (drop the chain's "end" mark: the wavelet kernels follow)
-    s->timer.mark("k_wv_scatter");
     if (n >= ((size_t)65535 * WS_T) || nf > 65535) return done(MIC_ERR_UNSUPPORTED);
+    s->timer.mark("k_rle_walk_parts+fix+compact");
+    hipLaunchKernelGGL(k_rle_walk_parts, dim3(WP_PARTS, (unsigned)nf), dim3(64), 0, s->stream, (MicUnit *)s->units.p);
+    hipLaunchKernelGGL(k_rle_walk_fix, dim3((unsigned)nf), dim3(64), 0, s->stream, (MicUnit *)s->units.p);
+    hipLaunchKernelGGL(k_rle_walk_compact, dim3(WP_PARTS, (unsigned)nf), dim3(256), 0, s->stream, (MicUnit *)s->units.p);
+    s->timer.mark("k_wv_scatter");
     hipLaunchKernelGGL(k_wv_scatter, dim3((unsigned)((n + WS_T - 1) / WS_T), (unsigned)nf), dim3(1024), 0, s->stream, (MicUnit *)s->units.p, A, d);
     s->timer.mark("k_wv_expand+coeffs (escape frames)");
     hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1, 1);

@@ -26,6 +26,7 @@ out = (C.c_uint32 * 32)()
 L.mic_hip_debug_unit.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
 for i in range(min(nf, 3)):
     L.mic_hip_debug_unit(sess._h, i, out)
+    print('unit', i, 'ntok', out[0], 'nseg', out[12], 'nsym', out[13], 'dbg8..15', [out[16 + k] for k in range(8, 16)])
     d = [out[16 + k] * 16 for k in range(5)]
     if d[4]:
         print("unit", i, "cycles per chunk: rounds %.0f  ring stores %.0f  loads %.0f  state stores %.0f  (chunks %d)" % tuple([d[k] / (d[4] / 16) for k in range(4)] + [d[4] // 16]))
