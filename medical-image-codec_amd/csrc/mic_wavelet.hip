@@ -61,38 +61,54 @@ __device__ __forceinline__ int32_t wv_sample(Get c, int n, int k) {
     return c(n_low + i) + ((l + r) >> 1);
 }
 
-// One thread per PAIR of outputs (smooth i, detail i): both come from the same five inputs x[2i-2 .. 2i+2].  Grid: x = pairs (rows
-// pass) or columns (columns pass) in groups of 256, y = rows or pairs, z = frame of the batch; no division anywhere.
+// One thread per PAIR of outputs (smooth i, detail i): both come from the same five inputs x[2i-2 .. 2i+2].  A group works on a
+// block of rows (rows pass: WV_RPB rows of 256 pairs) or on a strip of pairs down 256 columns (columns pass: WV_SP pairs, the
+// window x[2i], d[i-1] carried in registers: two loads per pair instead of five) -- a group per single row was bound by the rate
+// at which groups are dispatched (5.5 million of them per transform), not by memory.  No division anywhere.
 // FROM_U16: level 0 reads the 16-bit pixels themselves (no widening pass); TO_U16: the last inverse pass stores 16-bit pixels.
+#define WV_RPB 8
+#define WV_SP 16
 // rows of the r x c region: src -> dst, de-interleaved [low | high]   (waveletu16.go:170-182)
 template <bool FROM_U16>
 __global__ void __launch_bounds__(256) k_wv_fwd_rows(const void *__restrict__ src_, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
     const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (i >= n_low) return;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int y = (int)blockIdx.y; y < r; y += (int)gridDim.y) {
-            const size_t ro = (size_t)f * fs + (size_t)y * stride;
-            int32_t sv, dv = 0;
-            if (FROM_U16) { const uint16_t *row = (const uint16_t *)src_ + ro; auto x = [&](int j) { return (int32_t)row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
-            else { const int32_t *row = (const int32_t *)src_ + ro; auto x = [&](int j) { return row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
-            dst[ro + i] = sv;
-            if (2 * i + 1 < c) dst[ro + n_low + i] = dv;
-        }
+        for (int y0 = (int)blockIdx.y * WV_RPB; y0 < r; y0 += (int)gridDim.y * WV_RPB)
+#pragma unroll 4
+            for (int y = y0; y < min(y0 + WV_RPB, r); y++) {
+                const size_t ro = (size_t)f * fs + (size_t)y * stride;
+                int32_t sv, dv = 0;
+                if (FROM_U16) { const uint16_t *row = (const uint16_t *)src_ + ro; auto x = [&](int j) { return (int32_t)row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
+                else { const int32_t *row = (const int32_t *)src_ + ro; auto x = [&](int j) { return row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
+                dst[ro + i] = sv;
+                if (2 * i + 1 < c) dst[ro + n_low + i] = dv;
+            }
 }
-// columns of the r x c region   (waveletu16.go:183-208)
+// columns of the r x c region   (waveletu16.go:183-208): a thread walks WV_SP pairs down its column
 __global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
     const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
     if (xcol >= c) return;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int i = (int)blockIdx.y; i < n_low; i += (int)gridDim.y) {
+        for (int i0 = (int)blockIdx.y * WV_SP; i0 < n_low; i0 += (int)gridDim.y * WV_SP) {
             const int32_t *col = src + (size_t)f * fs + xcol;
-            auto x = [&](int j) { return col[(size_t)j * stride]; };
-            const int32_t sv = wv_s(x, r, i);
-            int32_t dv = 0;
-            if (2 * i + 1 < r) dv = wv_d(x, r, i);
             int32_t *o = dst + (size_t)f * fs + xcol;
-            o[(size_t)i * stride] = sv;
-            if (2 * i + 1 < r) o[(size_t)(n_low + i) * stride] = dv;
+            auto x = [&](int j) { return col[(size_t)j * stride]; };
+            int32_t x2i = x(2 * i0), dprev = (i0 > 0) ? wv_d(x, r, i0 - 1) : 0;
+            const int i1 = min(i0 + WV_SP, n_low);
+            for (int i = i0; i < i1; i++) {
+                int32_t d_right, xe2 = x2i;
+                const bool has_d = 2 * i + 1 < r;
+                if (has_d) {                                               // wv_d(i) with x[2i] from the window
+                    const int32_t xo = x(2 * i + 1);
+                    if (2 * i + 2 < r) xe2 = x(2 * i + 2);
+                    d_right = xo - ((x2i + xe2) >> 1);
+                } else d_right = (i > 0) ? dprev : 0;
+                const int32_t d_left = (i > 0) ? dprev : d_right;
+                o[(size_t)i * stride] = x2i + ((d_left + d_right + 2) >> 2);   // wv_s(i)
+                if (has_d) { o[(size_t)(n_low + i) * stride] = d_right; dprev = d_right; }
+                x2i = xe2;
+            }
         }
 }
 // inverse: columns first, then rows   (waveletu16.go:213-257); a thread restores samples 2i and 2i+1 of its line
@@ -108,13 +124,35 @@ __global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *__restrict__
     const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
     if (xcol >= c) return;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int i = (int)blockIdx.y; i < n_low; i += (int)gridDim.y) {
+        for (int i0 = (int)blockIdx.y * WV_SP; i0 < n_low; i0 += (int)gridDim.y * WV_SP) {
             const int32_t *col = src + (size_t)f * fs + xcol;
-            auto cf = [&](int j) { return col[(size_t)j * stride]; };
-            int32_t ev, od; wv_pair(cf, r, i, ev, od);
             int32_t *o = dst + (size_t)f * fs + xcol;
-            o[(size_t)(2 * i) * stride] = ev;
-            if (2 * i + 1 < r) o[(size_t)(2 * i + 1) * stride] = od;
+            auto cf = [&](int j) { return col[(size_t)j * stride]; };
+            if (r < 2) { o[0] = cf(0); continue; }
+            // even sample i = c(i) - ((d(i-1) + d(i) + 2) >> 2) with the edge rules of wv_even; odd sample i = d(i) + ((even i + even i+1) >> 1):
+            // the strip carries d(i-1) and even(i) down the column and looks one even sample ahead
+            const int i1 = min(i0 + WV_SP, n_low);
+            int32_t dprev = (i0 > 0) ? cf(n_low + i0 - 1) : 0;
+            int32_t dcur = 0, ev;
+            {
+                const bool has_d = 2 * i0 + 1 < r;
+                if (has_d) dcur = cf(n_low + i0);
+                const int32_t d_right = has_d ? dcur : ((i0 > 0) ? dprev : 0), d_left = (i0 > 0) ? dprev : d_right;
+                ev = cf(i0) - ((d_left + d_right + 2) >> 2);
+            }
+            for (int i = i0; i < i1; i++) {
+                o[(size_t)(2 * i) * stride] = ev;
+                if (2 * i + 1 >= r) break;                                 // (the line's last sample was an even one)
+                int32_t evn = ev, dnext = 0;
+                if (2 * i + 2 < r) {                                       // even sample i + 1
+                    const bool has_d = 2 * (i + 1) + 1 < r;
+                    if (has_d) dnext = cf(n_low + i + 1);
+                    const int32_t d_right = has_d ? dnext : dcur;          // (i + 1 > 0: the left neighbour d(i) exists)
+                    evn = cf(i + 1) - ((dcur + d_right + 2) >> 2);
+                }
+                o[(size_t)(2 * i + 1) * stride] = dcur + ((ev + evn) >> 1);
+                dprev = dcur; dcur = dnext; ev = evn;
+            }
         }
 }
 template <bool TO_U16>
@@ -122,14 +160,16 @@ __global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *__restrict__
     const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (i >= n_low) return;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int y = (int)blockIdx.y; y < r; y += (int)gridDim.y) {
-            const size_t ro = (size_t)f * fs + (size_t)y * stride;
-            const int32_t *row = src + ro;
-            auto cf = [&](int j) { return row[j]; };
-            int32_t ev, od; wv_pair(cf, c, i, ev, od);
-            if (TO_U16) { uint16_t *o = (uint16_t *)dst_ + ro; o[2 * i] = (uint16_t)ev; if (2 * i + 1 < c) o[2 * i + 1] = (uint16_t)od; }
-            else { int32_t *o = (int32_t *)dst_ + ro; o[2 * i] = ev; if (2 * i + 1 < c) o[2 * i + 1] = od; }
-        }
+        for (int y0 = (int)blockIdx.y * WV_RPB; y0 < r; y0 += (int)gridDim.y * WV_RPB)
+#pragma unroll 4
+            for (int y = y0; y < min(y0 + WV_RPB, r); y++) {
+                const size_t ro = (size_t)f * fs + (size_t)y * stride;
+                const int32_t *row = src + ro;
+                auto cf = [&](int j) { return row[j]; };
+                int32_t ev, od; wv_pair(cf, c, i, ev, od);
+                if (TO_U16) { uint16_t *o = (uint16_t *)dst_ + ro; o[2 * i] = (uint16_t)ev; if (2 * i + 1 < c) o[2 * i + 1] = (uint16_t)od; }
+                else { int32_t *o = (int32_t *)dst_ + ro; o[2 * i] = ev; if (2 * i + 1 < c) o[2 * i + 1] = od; }
+            }
 }
 // (a frame the transform leaves untouched: zero levels)
 __global__ void __launch_bounds__(256) k_wv_load(const uint16_t *px, int32_t *a, size_t n) {
@@ -693,7 +733,7 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     if (applied == 0) hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
     { int r = rows, c = cols;
       for (int l = 0; l < applied; l++) {
-          const dim3 gr = lift_grid((c + 1) / 2, r, nf), gc = lift_grid(c, (r + 1) / 2, nf);
+          const dim3 gr = lift_grid((c + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), gc = lift_grid(c, ((r + 1) / 2 + WV_SP - 1) / WV_SP, nf);
           if (l == 0) hipLaunchKernelGGL(k_wv_fwd_rows<true>, gr, dim3(256), 0, s->stream, (const void *)d_src, B, r, c, cols, n, nf);
           else hipLaunchKernelGGL(k_wv_fwd_rows<false>, gr, dim3(256), 0, s->stream, (const void *)A, B, r, c, cols, n, nf);
           hipLaunchKernelGGL(k_wv_fwd_cols, gc, dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n, nf);
@@ -768,9 +808,9 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     if (levels == 0) hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];
-        hipLaunchKernelGGL(k_wv_inv_cols, lift_grid(cc, (r + 1) / 2, nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n, nf);
-        if (l == 0) hipLaunchKernelGGL(k_wv_inv_rows<true>, lift_grid((cc + 1) / 2, r, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)d_dst, r, cc, cols, n, nf);
-        else hipLaunchKernelGGL(k_wv_inv_rows<false>, lift_grid((cc + 1) / 2, r, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)A, r, cc, cols, n, nf);
+        hipLaunchKernelGGL(k_wv_inv_cols, lift_grid(cc, ((r + 1) / 2 + WV_SP - 1) / WV_SP, nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n, nf);
+        if (l == 0) hipLaunchKernelGGL(k_wv_inv_rows<true>, lift_grid((cc + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)d_dst, r, cc, cols, n, nf);
+        else hipLaunchKernelGGL(k_wv_inv_rows<false>, lift_grid((cc + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)A, r, cc, cols, n, nf);
     }
     s->timer.mark("end");
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
