@@ -10,8 +10,9 @@
 //   2. the visit sequence: raw index J -> position (J*step) & mask, kept when <= highThreshold;
 //      a prefix sum of "kept" turns J into the visit number t, visit_pos[t] = position;
 //   3. the slot number of a position = its rank among the positions of the same symbol.  A
-//      symbol with few slots sorts them in registers; a symbol with many slots is ranked by the
-//      whole work-group through a position bitmap and a popcount prefix.
+//      symbol with few slots sorts them in registers; a symbol with many slots is ranked through a
+//      position bitmap and a popcount prefix: by a wave of its own when the table fits the LDS path
+//      (sixteen such symbols at a time), by the whole work-group otherwise.
 // Each (position, symbol, rank) triple is handed to an emit functor: the encoder fills
 // stateTable[cumul[s] + rank] = size + position, the decoder the transition of that position.
 #pragma once
@@ -122,9 +123,41 @@ __device__ int tp_build(const TpScratch<NormT, IdxT> &S, uint32_t symbol_len, ui
         }
     }
     __syncthreads();
-    // ---- 3b. symbols with many slots: bitmap + popcount prefix, whole group ----------------------------
+    // ---- 3b. symbols with many slots: bitmap + popcount prefix ----------------------------------------------------
     const uint32_t nbig = S.s_tmp[TP_WAVES];
     const uint32_t nwords = (size + 31) / 32;
+    if (sizeof(IdxT) == 2) {
+        // tableLog <= 13 (everything in LDS): a WAVE per symbol, sixteen symbols at a time, no group barrier.  The bitmap of a
+        // table is at most 256 words: wave w owns words [256 w, 256 w + 256) of the bitmap / prefix area (16 KiB) and 256
+        // 16-bit word prefixes behind the list of big symbols (at most size / 17 of them, 2 KiB of its 16).
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        uint32_t *bm = S.bitmap + wave * 256;
+        uint16_t *pf = (uint16_t *)(S.big_list + 1024) + wave * 256;
+        for (uint32_t bi = wave; bi < nbig; bi += TP_WAVES) {
+            const uint32_t s = S.big_list[bi];
+            const uint32_t v = (uint32_t)S.norm[s], a = (uint32_t)S.first_visit[s];
+            for (uint32_t w = lane; w < nwords; w += 64) bm[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < v; i += 64) { const uint32_t p = S.visit_pos[a + i]; atomicOr(&bm[p >> 5], 1u << (p & 31)); }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            uint32_t c[4], tot = 0;                                         // lane l owns words 4 l .. 4 l + 3
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t w = lane * 4 + (uint32_t)k; c[k] = (w < nwords) ? (uint32_t)__popc(bm[w]) : 0u; tot += c[k]; }
+            uint32_t run = tp_wave_incl_add(tot, lane) - tot;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t w = lane * 4 + (uint32_t)k; if (w < nwords) pf[w] = (uint16_t)run; run += c[k]; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < v; i += 64) {
+                const uint32_t p = S.visit_pos[a + i];
+                const uint32_t r = (uint32_t)pf[p >> 5] + (uint32_t)__popc(bm[p >> 5] & ((1u << (p & 31)) - 1u));
+                emit(p, s, r, v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        return MICD_OK;
+    }
+    // larger tables (scratch in HBM): the whole group per symbol
     for (uint32_t bi = 0; bi < nbig; bi++) {
         const uint32_t s = S.big_list[bi];
         const uint32_t v = (uint32_t)S.norm[s], a = (uint32_t)S.first_visit[s];
