@@ -452,7 +452,7 @@ struct PrSlot {
 // The ordinary class runs four units per group, one wave each with its own row buffer: a group's waves land on the four
 // SIMDs by construction, whereas single-wave groups pile up unevenly and the younger wave of a crowded SIMD starves.
 template <int WIDE>
-__global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units, int n_units, int w_lo, int w_hi) {
+__global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units, int n_units, int w_lo, int w_hi, uint32_t rb_dwords) {
     constexpr int WPG = WIDE ? 1 : 4;                            // waves (= units) per group
     const int ui = (int)blockIdx.x * WPG + (int)(threadIdx.x >> 6);
     if (ui >= n_units) return;
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
     const int W = u.w, H = u.h;
     if (W <= w_lo || W > w_hi) return;
     extern __shared__ uint32_t s_rowbuf_all[];                   // per wave: ngrp x PR_DW dwords
-    uint32_t *const s_rowbuf = s_rowbuf_all + (WIDE ? 0u : (threadIdx.x >> 6) * 4096u);   // 16 KiB per wave (8192 columns)
+    uint32_t *const s_rowbuf = s_rowbuf_all + (WIDE ? 0u : (threadIdx.x >> 6) * rb_dwords);   // 2 bytes per column and wave (launch class)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
     const uint32_t thr = u.dec_thr;
@@ -717,11 +717,13 @@ __global__ void __launch_bounds__(64) k_dec_predict_grad(MicUnit *units, int w_l
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad) {
     if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
-    // two row-buffer classes so that ordinary widths keep many waves per CU
+    // row-buffer classes so that ordinary widths keep many waves per CU: a row buffer is 2 bytes per column and unit, four units per
+    // group; up to 4032 columns that is 8 KiB per unit and twenty units per CU (a latency-bound kernel: one wave per unit)
     if (t) t->mark("k_dec_predict<0>");
-    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 0, 8192 - PR_K);
+    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 4096 * 2, stream, d_units, n, 0, 4096 - PR_K, 2048u);
+    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 4096 - PR_K, 8192 - PR_K, 4096u);
     if (t) t->mark("k_dec_predict<wide>");
-    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W);
+    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
     if (any_grad) {
         if (t) t->mark("k_dec_predict_grad");
         static MicPerDeviceOnce once;

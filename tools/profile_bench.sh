@@ -13,8 +13,17 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT \
     -d $OUT/sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
 python3 bench.py --no-cpu --no-legs > $OUT/bench_plain.json 2> $OUT/plain.err
+# the other BASELINE configurations (bench.py's legs): kernel trace only
+rocprofv3 --kernel-trace --stats -d $OUT/legs -- python3 bench.py --no-cpu --legs-only > $OUT/bench_legs_trace.json 2> $OUT/legs.err
+LG=$(find $OUT/legs -name "*.db" | head -1)
+python3 - "$LG" $OUT/summary_legs_kernel_stats.csv <<'PY'
+import csv, sqlite3, sys
+rows = sqlite3.connect(sys.argv[1]).cursor().execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+w = csv.writer(open(sys.argv[2], "w", newline="")); w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us"])
+for n, c, t, a, mi, ma in rows: w.writerow([n, c] + ["%.3f" % (x / 1e3) for x in (t, a, mi, ma)])
+PY
 T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1); S=$(find $OUT/sq -name "*.db" | head -1)
 echo "dbs: $T $F $W $S"
 python3 tools/prof_summary.py "$T" "$F" "$W" $OUT/summary "$OUT/bench_trace.json" "$S"
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq   # the databases are large; the summaries are what is kept
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq $OUT/legs   # the databases are large; the summaries are what is kept
 ls -la $OUT
