@@ -74,8 +74,13 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
             const uint32_t w = (pos + lane < ntok) ? tok[pos + lane] : 0u;
             uint32_t j = 0;
             while (j < 64 && pos + j < ntok && outp < symcap) {
-                const uint32_t h = __builtin_amdgcn_readlane(w, (int)j);
-                if (h == 0 || nseg >= segcap) { err = 1; break; }        // count 0 is never written by an encoder
+                uint32_t h = __builtin_amdgcn_readlane(w, (int)j);
+                if (nseg >= segcap) { err = 1; break; }
+                // No encoder writes a count of 0, but the reference decodes one (DecodeNext2 keeps the count in a uint16: 0 passes as a run,
+                // is decremented to 65535 and counts down from there as a literal chunk): one symbol = the token behind the header, then the
+                // 65535 - midCount tokens behind that -- a literal chunk of 65536 - midCount symbols whose payload starts behind the header.
+                // (The walkers inside the entropy kernels stop at a zero and leave the stream to this one.)
+                if (h == 0) h = 65536u;
                 if (h <= mid) {                                          // same-run: count, value
                     if (pos + j + 1 >= ntok) { err = 1; break; }
                     if (j == 63) break;                                  // value not in the window: reload at the header

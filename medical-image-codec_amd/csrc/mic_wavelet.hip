@@ -282,8 +282,9 @@ __global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units, int mo
             const uint32_t w = (pos + lane < ntok) ? tok[pos + lane] : 0u;
             uint32_t j = 0;
             while (j < 64 && pos + j < ntok && outp < outlen) {
-                const uint32_t h = __builtin_amdgcn_readlane(w, (int)j);
-                if (h == 0 || nseg >= segcap) { err = 1; break; }
+                uint32_t h = __builtin_amdgcn_readlane(w, (int)j);
+                if (nseg >= segcap) { err = 1; break; }
+                if (h == 0) h = 65536u;                                  // the reference's reading of a zero count: a literal chunk of 65536 - midCount (mic_decode_px.hip)
                 if (h <= mid) {
                     if (pos + j + 1 >= ntok) { err = 1; break; }
                     if (j == 63) break;
@@ -305,7 +306,8 @@ __global__ void __launch_bounds__(WV_THREADS) k_wv_expand(MicUnit *units, int mo
     uint32_t bad = 0;
     for (uint32_t si = wave; si < nseg; si += WV_WAVES) {
         const uint2 r = seg[si];
-        const uint32_t h = tok[r.x];
+        uint32_t h = tok[r.x];
+        if (h == 0) h = 65536u;                                          // (a zero count: see the walker above)
         if (h <= mid) {
             const uint16_t v = tok[r.x + 1];
             for (uint32_t k = lane; k < h && r.y + k < outlen; k += 64) sym[r.y + k] = v;

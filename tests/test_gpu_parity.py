@@ -622,6 +622,88 @@ def test_wavelet_v2_escape_path_full_16bit(mic, mico, synth, gpu_ready):
     assert np.array_equal(px, img)
 
 
+def test_frame_streams_with_damaged_tokens_agree_with_the_oracle(mic, mico, synth, gpu_ready):
+    """Token streams no encoder writes (zero counts -- the reference reads one as a literal chunk of 65536 - midCount --, headers that
+    point past the end, streams that stop early), put through the entropy coder again so that the FSE stage accepts them: the GPU's
+    header walkers and the oracle's pull decoder (rledecompressu16.go:59-85) must make the same frame, or both an error, of each."""
+    rng = np.random.default_rng(9)
+    total = decodable = 0
+    for seed, noise, (h, w) in ((3, 2.0, (200, 320)), (4, 60.0, (130, 257)), (5, 10.0, (64, 96))):
+        img = synth.xr_like(cols=w, rows=h, depth=12, seed=seed, noise=noise)
+        tok = mico.delta_rle_compress(img, 4095)
+        for k in range(60):
+            t = tok.copy()
+            for _ in range(int(rng.integers(1, 5))):
+                i = int(rng.integers(1, t.size))
+                t[i] = (0, 1, 2, int(t[0]), int(t[0]) // 2 + 1, int(rng.integers(0, int(t[0]) + 1)))[int(rng.integers(0, 6))]
+            if k % 8 == 2:
+                t = t[: int(rng.integers(3, t.size))]
+            rc, stream = mico.fse_compress(t, 2)
+            if rc:
+                continue
+            rc_o, want = mico.decompress_single_frame(stream, w, h)
+            try:
+                got, rc_g = mic.decompress_single_frame(stream, w, h), 0
+            except mic.MicError as e:
+                got, rc_g = None, e.code
+            assert (rc_g == 0) == (rc_o == 0), (seed, k, rc_g, rc_o)
+            if rc_o == 0:
+                assert np.array_equal(got, want), (seed, k)
+                decodable += 1
+            total += 1
+    assert total > 100 and decodable > 40 and total - decodable > 20
+
+
+def test_wavelet_v2_mutated_streams_agree_with_the_oracle(mic, mico, synth, gpu_ready):
+    """The decode tail walks the RLE headers in parts that start at arbitrary tokens (mic_wavelet.hip): whatever a damaged stream
+    makes of that -- an error, or pixels -- must be what the oracle's serial decoder makes of it.  Frames big enough for several
+    parts, smooth (run-dense) and noisy (literal-dense), byte flips all over the stream, truncations, a wrong symbol count."""
+    rng = np.random.default_rng(5)
+    checked = errors = 0
+    for seed, noise, shape in ((3, 2.0, (300, 420)), (4, 40.0, (257, 389)), (5, 5.0, (96, 64))):
+        img = synth.xr_like(cols=shape[1], rows=shape[0], depth=12, seed=seed, noise=noise)
+        rc, good = mico.wavelet_v2_compress(img, 4095, 4)
+        assert rc == 0
+        px, _, _ = mic.wavelet_v2_decompress(good)
+        assert np.array_equal(px, img)
+        cases = [good[:n] for n in (11, 13, 20, len(good) // 2, len(good) - 1)]
+        for _ in range(40):
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(11, len(b)))
+                b[i] ^= 1 << int(rng.integers(0, 8))
+            cases.append(bytes(b))
+        # ... and damage to the TOKENS themselves, coded again: streams the entropy stage accepts, with headers that point anywhere
+        # (zero counts, run headers at the end, literal chunks past it, a symbol count that is too large or too small)
+        rc, tok = mico.fse_decompress_auto(good[11:], img.size * 4)
+        assert rc == 0
+        for k in range(40):
+            t = tok.copy()
+            for _ in range(int(rng.integers(1, 5))):
+                i = int(rng.integers(0, t.size))
+                t[i] = (0, 1, 2, int(t[0]), int(t[0]) // 2 + 1, int(rng.integers(0, int(t[0]) + 1)))[int(rng.integers(0, 6))] if i else t[i]
+            if k % 8 == 0: t[2] = (int(t[2]) + int(rng.integers(1, 50))) & 0xFFFF          # announces more symbols than there are
+            if k % 8 == 1: t[2] = max(int(t[2]) - int(rng.integers(1, 50)), 0)              # ... fewer
+            if k % 8 == 2: t = t[: int(rng.integers(3, t.size))]                             # tokens end early
+            rc, stream = mico.fse_compress(t, 4)
+            if rc == 0:
+                cases.append(good[:11] + stream)
+        for c in cases:
+            rc_o, want = mico.wavelet_v2_decompress(c)
+            try:
+                got, _, _ = mic.wavelet_v2_decompress(c)
+                rc_g = 0
+            except mic.MicError as e:
+                rc_g, got = e.code, None
+            assert (rc_g == 0) == (rc_o == 0), (seed, rc_g, rc_o, len(c))
+            if rc_o == 0:
+                assert np.array_equal(got, want)
+            else:
+                errors += 1
+            checked += 1
+    assert checked > 200 and errors > 20 and checked - errors > 20
+
+
 # ---- gradient-adaptive predictor and PICA (deltagradrlecompressu16.go, parallelstripsadaptive.go) -------------------------
 def _pica_images(synth):
     mr = np.fromfile(os.path.join(GOLDEN, "MR_256_256_image.bin"), dtype="<u2").reshape(256, 256)
