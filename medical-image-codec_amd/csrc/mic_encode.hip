@@ -788,7 +788,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     uint16_t *stv = u.sym;
     const uint32_t hdr_len = u.hdr_len;
     uint8_t *bits_base = u.blob + 6 + hdr_len;
-    const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 7);           // the bit grid starts at an 8-byte boundary: the pack pass stores 64 bits at a time
+    const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 15);          // the bit grid starts at a 16-byte boundary: the pack pass stores pairs of 64-bit units
     uint32_t *words = (uint32_t *)(bits_base - lead);
     const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
     const uint32_t nblk = (n + TE_BLK - 1) / TE_BLK;
@@ -946,7 +946,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
 #ifdef MIC_GATE_REG
     // diagnostic build: every thread forms the verdict from its own registers (the variant that misbehaved in round 1)
     int rc_reg = MICD_OK;
-    if ((8ull * lead + total_bits + 127) / 32 >= words_cap) rc_reg = MICD_ERR_CAPACITY;
+    if ((8ull * lead + total_bits + 255) / 32 >= words_cap) rc_reg = MICD_ERR_CAPACITY;
     else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc_reg = MICD_ERR_INCOMPRESSIBLE;
 #ifdef MIC_GATE_REG2
     if (rc_reg == MICD_ERR_CAPACITY) { total_bytes_out = total_bytes; rc_out = rc_reg; return; }   // (the verdict itself is used after the pack loop)
@@ -959,7 +959,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     // the verdict goes through LDS so that every thread (and the caller) sees one value
     if (tid == 0) {
         int rc0 = MICD_OK;
-        if ((8ull * lead + total_bits + 127) / 32 >= words_cap) rc0 = MICD_ERR_CAPACITY;
+        if ((8ull * lead + total_bits + 255) / 32 >= words_cap) rc0 = MICD_ERR_CAPACITY;
         else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc0 = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
         s_scan[TE_WAVES] = (uint32_t)rc0; s_scan[TE_WAVES + 1] = total_bytes;
     }
@@ -971,16 +971,26 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
 #endif
     MIC_STAMP_AT(u, 10);
     // ---- 4. pack -------------------------------------------------------------------------------------
-    // 64 bits per store: the memory counters charge every store instruction a 32-byte write whatever its width or its neighbours
-    // (1.74 GB of output as dword stores = 435 M x 32 bytes = 13.9 GB of WRITE_SIZE, measured in two orders of the same stores), so
-    // the pass makes half as many.  A 64-bit unit is stored by the thread owning its first bit; the threads that only reach into
-    // it OR their bits in after a barrier.
+    // 64-bit units, stored in aligned PAIRS (16 bytes): the memory counters charge every store instruction a 32-byte write whatever
+    // its width or its neighbours (1.74 GB of output as dword stores = 435 M x 32 bytes = 13.9 GB of WRITE_SIZE, measured in two
+    // orders of the same stores; as 64-bit stores 8.3 GB and 6.4 -> 5.2 ms), so the pass makes a quarter as many.  A unit is stored by
+    // the thread owning its first bit; the threads that only reach into it OR their bits in after a barrier.
     unsigned long long *const words64 = (unsigned long long *)words;
     const uint32_t first_q = (uint32_t)(gstart >> 6);
     const bool own_first = (gstart & 63) == 0;
     uint32_t q = first_q;
     uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 63);
     uint64_t lead_val = 0; bool have_lead = false;
+    uint64_t pend = 0; bool have_pend = false;                            // the even unit of a pair, waiting for its odd partner
+    typedef unsigned long long te_u2 __attribute__((ext_vector_type(2)));
+    auto emit = [&](uint64_t v) {                                          // unit q is complete (or the thread's last, partial one)
+        if (q == first_q && !own_first) { lead_val = v; have_lead = true; }
+        else if (q & 1u) {
+            if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(te_u2 *)(words64 + (q - 1)) = pr; have_pend = false; }
+            else words64[q] = v;
+        } else { pend = v; have_pend = true; }
+        q++;
+    };
     {
         uint32_t stp[N];
         const uint32_t lastown = (nblk + per - 1) / per;   // threads 0 .. lastown-1 own tokens; s_E[T-1] was overwritten for the trailer
@@ -1000,19 +1010,16 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
                     acc |= (uint64_t)bv << filled;
                     const uint32_t nf = filled + nb;
                     if (nf >= 64) {
-                        if (q > first_q || own_first) words64[q] = acc;
-                        else { lead_val = acc; have_lead = true; }
+                        emit(acc);
                         acc = (uint64_t)(bv >> (64u - filled));              // what did not fit (filled >= 48 here: a shift by 1..16)
-                        filled = nf - 64; q++;
+                        filled = nf - 64;
                     } else filled = nf;
                 }
             }
         }
     }
-    if (mybits > 0 && filled > 0) {
-        if (q > first_q || own_first) words64[q] = acc;                   // owner's partial unit
-        else { lead_val = acc; have_lead = true; }
-    }
+    if (mybits > 0 && filled > 0) emit(acc);                             // the thread's last, partial unit
+    if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
     __threadfence_block();
     __syncthreads();
     if (have_lead && lead_val) atomicOr(&words64[first_q], (unsigned long long)lead_val);
