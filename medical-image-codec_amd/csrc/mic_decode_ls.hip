@@ -8,13 +8,13 @@
 // instruction per ~5 cycles whatever its lanes do.  The earlier kernel (k_dec_tans_duo, mic_decode.hip) ran every lane of a
 // wave through the same values -- two distinct streams per 64 lanes, N table look-ups issued one after the other -- so it
 // was bound by instructions issued per symbol and got slower with more states.  Here lane g*N + k of a wave owns state k of
-// the wave's stream g (three streams per wave, three waves per group, one group per CU):
+// the wave's stream g (three streams per wave, three waves per group, one group per CU; N = 4: lane 16 g + k, a DPP row a stream):
 //   * a round = ONE table look-up instruction for all N states of all three streams, nbBits from v_ffbh, the offset of a
 //     state's bits inside the round from a DPP prefix sum over the N lanes of its stream (quad_perm / row_shr: no LDS, no
 //     readlane), the bits from a funnel shift of the stream's bit window, kept in a 256-dword LDS ring;
-//   * N = 2: the 32-bit window is read at the round's start position together with the table look-ups, so a round costs one
-//     LDS round trip; N = 4 / 8: every lane reads its own window at its own bit position once the prefix sum is known:
-//     two LDS round trips for 4 / 8 symbols, so more states decode FASTER;
+//   * N = 2 and N = 4: the round's window (32 / 64 bits) is read at the round's start position together with the table look-ups,
+//     so a round costs one LDS round trip (115 cycles for two symbols, 136 for four); N = 8: every lane reads its own window at
+//     its own bit position once the prefix sum is known: two round trips for eight symbols.  More states decode FASTER;
 //   * the lanes of a wave that own no state clone stream 0 (same addresses: LDS broadcasts); all 64 lanes share the
 //     per-chunk work, which is small: ring refill (64 dwords per stream and 128 symbols, prefetched a chunk ahead) and one
 //     coalesced 256-byte store of the chunk's 128 STATES per stream.
@@ -24,7 +24,7 @@
 // cycles per chunk; stamps: tools/time_dec.py on an LS_STAMP build).  k_dec_translate has the table in LDS, streams the
 // states once, and walks the RLE headers (rledecompressu16.go:59-85) on tiles it already holds in LDS.
 // Streams come from a compacted per-class list (k_dec_classify), so a launch only touches the units of its class.
-// LDS per stream: ring 1024 B | 2 mirror dwords + pad, 16 B | stage 256 B (128 u16 states) | table 2 << 13 B.
+// LDS per stream: ring 1024 B (2048 at tableLog 16) | 2 mirror dwords + pad, 16 B | stage 256 B (128 u16 states) | table 2 << tableLog B.
 #include <type_traits>
 #include "mic_dev.h"
 #include "mic_launch.h"
