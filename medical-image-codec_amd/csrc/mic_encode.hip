@@ -778,7 +778,7 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 // tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
 // TTL: the per-symbol records (symbolTT / rANS freq+bias) were copied to LDS (alphabets up to TE_TT_SYMS);
 // otherwise every coding step gathers them from HBM.
-template <int N, bool RANS, bool TTL>
+template <int N, bool RANS, bool TTL, int T>
 __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, const int32_t *s_ttfind,
                           uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -792,7 +792,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     uint32_t *words = (uint32_t *)(bits_base - lead);
     const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
     const uint32_t nblk = (n + TE_BLK - 1) / TE_BLK;
-    const uint32_t per = (nblk + TE_THREADS - 1) / TE_THREADS;
+    const uint32_t per = (nblk + T - 1) / T;
     const uint32_t b_hi = (tid * per < nblk) ? nblk - tid * per : 0;
     const uint32_t b_lo = (b_hi > per) ? b_hi - per : 0;
     // ---- 1. speculative walk from the guessed state 2^tl --------------------------------------
@@ -879,7 +879,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
     MIC_STAMP_AT(u, 8);
     // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
-    for (uint32_t round = 0; round < TE_THREADS; round++) {
+    for (uint32_t round = 0; round < T; round++) {
         __syncthreads();
         int changed = 0;
         uint32_t e_out[N], st2[N]; bool any = false;
@@ -928,7 +928,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     if (tid == 0) {
         // last thread that owns tokens
         uint32_t last = (nblk + per - 1) / per; if (last > 0) last--;
-        for (int k = 0; k < N; k++) s_E[TE_THREADS - 1][k] = s_E[last][k];
+        for (int k = 0; k < N; k++) s_E[T - 1][k] = s_E[last][k];
     }
     __threadfence_block();
     __syncthreads();
@@ -939,7 +939,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     __syncthreads();
     uint32_t woff = 0, sym_bits = 0;
 #pragma unroll
-    for (int wv = 0; wv < TE_WAVES; wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
+    for (int wv = 0; wv < (T / 64); wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
     const uint64_t gstart = 8ull * lead + woff + incl - mybits;            // first grid bit of this thread
     const uint64_t total_bits = (uint64_t)sym_bits + (uint64_t)N * tl + 1;
     const uint32_t total_bytes = (uint32_t)((total_bits + 7) >> 3);
@@ -961,11 +961,11 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         int rc0 = MICD_OK;
         if ((8ull * lead + total_bits + 255) / 32 >= words_cap) rc0 = MICD_ERR_CAPACITY;
         else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc0 = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
-        s_scan[TE_WAVES] = (uint32_t)rc0; s_scan[TE_WAVES + 1] = total_bytes;
+        s_scan[(T / 64)] = (uint32_t)rc0; s_scan[(T / 64) + 1] = total_bytes;
     }
     __syncthreads();
-    const int rc = (int)s_scan[TE_WAVES];
-    total_bytes_out = s_scan[TE_WAVES + 1];
+    const int rc = (int)s_scan[(T / 64)];
+    total_bytes_out = s_scan[(T / 64) + 1];
     rc_out = rc;
     if (rc != MICD_OK) return;
 #endif
@@ -1031,7 +1031,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         const uint64_t end = pos + (uint64_t)N * tl + 1;
         for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
         for (int k = N - 1; k >= 0; k--) {
-            const uint64_t v = (uint64_t)((uint32_t)s_E[TE_THREADS - 1][k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
+            const uint64_t v = (uint64_t)((uint32_t)s_E[T - 1][k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
             const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
             words[wi] |= (uint32_t)(v << sh);
             if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
@@ -1045,25 +1045,38 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     MIC_STAMP_AT(u, 11);
 }
 
-template <int TLHI>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI)
-__global__ void __launch_bounds__(TE_THREADS, 4) k_enc_tans_wg(MicUnit *units) {
-    constexpr uint32_t tl_lo = (TLHI == 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
+// Small units get a group of ONE wave (T = 64, a 1024-symbol coding-record area: 24 KiB of LDS, six groups per CU): cut into 512 ranges
+// a 35 k-token plane leaves 70 tokens per thread, walks from different states do not merge inside such a range and every correction
+// ripples on at one barrier round per range (140 rounds, 80 % of the kernel on MIC3 planes); 64 ranges of 550 tokens merge, and
+// six units per CU instead of two share it.
+#define TE_SMALL_NTOK 98304u
+#define TE_SMALL_SYMS 1024u
+// class of a unit: 0 = the 512-thread instance, 1 = one wave, tableLog <= 12 and <= 512 symbols (12 KiB of LDS: thirteen groups per CU --
+// 8-bit planes), 2 = one wave, the other small units (24 KiB: six per CU)
+__device__ __forceinline__ int te_small_class(const MicUnit &u) {
+    if (u.ntok > TE_SMALL_NTOK || u.table_log > 13 || u.symbol_len > TE_SMALL_SYMS) return 0;
+    return (u.table_log <= 12 && u.symbol_len <= 512u) ? 1 : 2;
+}
+template <int TLHI, int T, int TTS>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI); threads; LDS coding records
+__global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
+    constexpr uint32_t tl_lo = (TLHI <= 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ uint16_t s_stab[];
-    __shared__ uint16_t s_E[TE_THREADS][8];
-    __shared__ uint32_t s_scan[TE_WAVES + 2];
+    __shared__ uint16_t s_E[T][8];
+    __shared__ uint32_t s_scan[(T / 64) + 2];
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.nstates_used != 0) return;
     const uint32_t tl = u.table_log;
     if (tl < tl_lo || tl > tl_hi) return;
+    if (TLHI <= 13 && te_small_class(u) != (T == 64 ? (TLHI == 12 ? 1 : 2) : 0)) return;   // (small units: the one-wave instances)
     const uint32_t tid = threadIdx.x;
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
-    if (u.nstates != 108) for (uint32_t i = tid; i < size; i += TE_THREADS) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
+    if (u.nstates != 108) for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
     uint32_t *s_ttnb = (uint32_t *)(s_stab + (1u << TLHI));
-    int32_t *s_ttfind = (int32_t *)(s_ttnb + TE_TT_SYMS);
-    const bool ttl = TLHI <= 15 && u.symbol_len <= TE_TT_SYMS;
-    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += TE_THREADS) { s_ttnb[i] = u.tt_nb[i]; s_ttfind[i] = u.tt_find[i]; }
+    int32_t *s_ttfind = (int32_t *)(s_ttnb + TTS);
+    const bool ttl = TLHI <= 15 && u.symbol_len <= TTS;
+    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += T) { s_ttnb[i] = u.tt_nb[i]; s_ttfind[i] = u.tt_find[i]; }
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
     const bool rans = u.nstates == 108;                                          // rans8state.go: 8 lanes, magic FF 08
@@ -1076,17 +1089,17 @@ __global__ void __launch_bounds__(TE_THREADS, 4) k_enc_tans_wg(MicUnit *units) {
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
             if (TLHI <= 15 && ttl) {
-                if (rans) te_encode<8, true, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, true>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
             } else {
-                if (rans) te_encode<8, true, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, false>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
             }
         }
         __syncthreads();
@@ -1180,17 +1193,20 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     if (variant != 100) {
         static MicPerDeviceOnce once;
         if (once.first()) {
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }
         if (t) t->mark("k_enc_tans_wg<13>");
-        hipLaunchKernelGGL(k_enc_tans_wg<13>, dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
+        hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
+        if (t) t->mark("k_enc_tans_wg<13, one wave>");
+        hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8, stream, d_units);
+        hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8, stream, d_units);
         if (t) t->mark("k_enc_tans_wg<other classes>");
-        hipLaunchKernelGGL(k_enc_tans_wg<14>, dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
-        hipLaunchKernelGGL(k_enc_tans_wg<15>, dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
-        hipLaunchKernelGGL(k_enc_tans_wg<16>, dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
+        hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
+        hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
+        hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
     }
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
