@@ -30,13 +30,14 @@
 #include "mic_launch.h"
 
 // Table-size classes: streams per wave x waves per group are what the LDS holds of 2 << tableLog byte tables.
-//   tableLog <= 13: 3 x 3 = nine streams (159 120 bytes) | 14: 2 x 2 (136 256) | 15: 1 x 2 (134 736) | 16: 1 x 1 (133 392)
+//   tableLog 13: 3 x 3 = nine streams (159 120 bytes) | 14: 2 x 2 (136 256) | 15: 1 x 2 (134 736) | 16: 1 x 1 (133 392)
+//   tableLog <= 12 (8 KiB tables: small units -- MIC3 planes, thin strips): 4 x 4 = sixteen streams (151 808)
 // At tableLog 16 a nextState needs 17 bits when the table has 0-bit entries (zeroBits): those streams stay with k_dec_tans_gl.
 #define LS_RING 0u
-#define LS_CLASSES MIC_CLS_CLASSES                 // 4 table-size classes x (N in 2,4,8) x (zeroBits)
+#define LS_CLASSES MIC_CLS_CLASSES                 // 5 table-size classes (tableLog 13, 14, 15, 16, <= 12) x (N in 2,4,8) x (zeroBits)
 template <int TL> struct LsGeom {
-    static constexpr int SPW = TL <= 13 ? 3 : TL == 14 ? 2 : 1;           // streams per wave
-    static constexpr int WAVES = TL <= 13 ? 3 : TL == 16 ? 1 : 2;        // waves per group (one group per CU: the LDS is full)
+    static constexpr int SPW = TL <= 12 ? 4 : TL == 13 ? 3 : TL == 14 ? 2 : 1;   // streams per wave
+    static constexpr int WAVES = TL <= 12 ? 4 : TL == 13 ? 3 : TL == 16 ? 1 : 2;  // waves per group (one group per CU: the LDS is full)
     // The bit window's ring: blocks of 64 dwords.  A chunk of 128 symbols takes at most 4 * tableLog dwords off it (+ 2 the window
     // reads reach below the position): under a block up to tableLog 15, so three blocks stored (the position's, one above, one below)
     // and a fourth in flight do; at tableLog 16 a chunk can take a whole block, so the ring is twice as long and runs a block deeper.
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, in
                 if (u.bits_off >= u.comp_len) u.status = MICD_ERR_CORRUPT;
                 else if (u.comp_len - u.bits_off < (1u << 27)) {            // 32-bit bit positions here; the serial kernel takes longer ones
                     if (u.comp_in[u.comp_len - 1] == 0) u.status = MICD_ERR_CORRUPT;
-                    else cls = (tl <= 13 ? 0 : (int)tl - 13) * 6 + (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
+                    else cls = (tl <= 12 ? 4 : (int)tl - 13) * 6 + (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
                 }
             }
         }
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(64 * LsGeom<TL>::WAVES) k_dec_tans_ls(MicUnit 
     // LDS queue at the top of a round, oldest first: entry, window (2), stage.
 #define LS_CHUNK4() do { \
         uint32_t e, c, a, m, p, at, tot; \
-        const uint64_t ls_em = LS_SPW == 3 ? 0x0000000F000F000Full : LS_SPW == 2 ? 0x00000000000F000Full : 0xFull; \
+        const uint64_t ls_em = LS_SPW == 4 ? 0x000F000F000F000Full : LS_SPW == 3 ? 0x0000000F000F000Full : LS_SPW == 2 ? 0x00000000000F000Full : 0xFull; \
         q -= 32; \
         asm volatile(".set ls_off, 8\n\t" \
                      "s_mov_b64 exec, %[em]\n\t" \
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
 
 template <int N, bool ZB, int TL>
 static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream) {
-    constexpr int cls = (TL <= 13 ? 0 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
+    constexpr int cls = (TL <= 12 ? 4 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
     constexpr int per = LsGeom<TL>::WAVES * LsGeom<TL>::SPW;
     static MicPerDeviceOnce once;
     if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, LsGeom<TL>::LDS);
@@ -691,6 +692,8 @@ void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, 
     launch_ls_class<2, false, 13>(d_units, n, d_list, d_count, stream);
     if (t) t->mark("k_dec_tans_ls<other,13>");
     launch_ls_tl<13>(d_units, n, d_list, d_count, stream, true);
+    if (t) t->mark("k_dec_tans_ls<..12>");
+    launch_ls_tl<12>(d_units, n, d_list, d_count, stream, false);
     if (t) t->mark("k_dec_tans_ls<14..16>");
     launch_ls_tl<14>(d_units, n, d_list, d_count, stream, false);
     launch_ls_tl<15>(d_units, n, d_list, d_count, stream, false);

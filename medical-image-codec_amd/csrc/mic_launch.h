@@ -48,7 +48,7 @@ struct MicTimer {
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 // d_cls: per-session scratch of MIC_CLS_INTS(n) ints for the per-class unit lists of the lane-per-state tANS decoder (mic_decode_ls.hip)
 #define MIC_CLS_HEAD 32
-#define MIC_CLS_CLASSES 24
+#define MIC_CLS_CLASSES 30
 #define MIC_CLS_INTS(n) (MIC_CLS_HEAD + MIC_CLS_CLASSES * (size_t)(n))
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls);
 void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t);
