@@ -62,6 +62,7 @@ struct MicUnit {
                               // and in `flags` the segment that holds every 8192nd symbol
     uint32_t  wv_slow;        // WaveletV2: this frame takes the one-group kernels (escape words in its stream, or a stream the walker refused)
     uint32_t  wv_zmax;        // WaveletV2 encode: largest zigzag symbol of the frame
+    uint32_t  hist_hi;        // encode: every token the tokeniser counted is below this (0: unknown -- all 65536 bins are scanned)
     // ---- results -----------------------------------------------------------------
     uint32_t ntok;            // number of u16 in tok
     uint32_t blob_len;

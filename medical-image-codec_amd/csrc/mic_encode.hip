@@ -196,10 +196,11 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
+    __shared__ uint32_t s_tmaxall;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
     if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
-    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last[0] = s_last[1] = 0; }
+    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last[0] = s_last[1] = 0; s_tmaxall = 0; }
     const int depth = mic_len16(u.max_value);
     if (!SRC && (u.w <= 0 || u.h <= 0)) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
     if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
@@ -229,9 +230,10 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     for (uint32_t i = tid; i < 2 * (TK_WIN + 16); i += TK_THREADS) (&xs2[0][0])[i] = 0;
     if (tid < 16) { s_cnt[tid] = 0; s_run[tid] = 0; s_str[tid] = 0; s_tc[tid] = 0; }
     __syncthreads();
+    uint32_t tmax = 0;                                      // largest token counted outside the LDS window
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
-        if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u); else atomicAdd(&ghist[v], 1u);
+        if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u); else { atomicAdd(&ghist[v], 1u); tmax = max(tmax, v); }
     };
     if (tid == 0) {
         if (SRC) {
@@ -551,9 +553,14 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t vv = s_hist[i]; if (vv) atomicAdd(&ghist[hlo + i], vv); }
+    // what k_enc_tables_wg has to scan of the 65536 bins: the window and whatever was counted outside it
+    tmax = tk_wave_incl_max(tmax, lane);
+    if (lane == 63 && tmax) atomicMax(&s_tmaxall, tmax);
+    __syncthreads();
     if (tid == 0) {
         if (s_ovf || outp > cap) u.status = MICD_ERR_CAPACITY;
         else u.ntok = outp;
+        u.hist_hi = min(65536u, max(hlo + (uint32_t)TK_HWIN, s_tmaxall + 1u));
     }
 }
 

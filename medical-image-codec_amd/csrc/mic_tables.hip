@@ -410,7 +410,8 @@ __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
     uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
     // ---- histogram scan: symbolLen and maxCount (fsecompressu16.go:438-462) -------------------------
     uint32_t m = 0, sl = 0;
-    for (uint32_t i = tid; i <= MIC_MAXSYM; i += TP_THREADS) {
+    const uint32_t hist_hi = (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u;   // (the tokeniser's bound on what it counted)
+    for (uint32_t i = tid; i < hist_hi; i += TP_THREADS) {
         const uint32_t c = u.hist[i];
         if (c) { m = max(m, c); sl = max(sl, i + 1); }
     }
