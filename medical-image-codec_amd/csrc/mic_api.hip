@@ -70,10 +70,10 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
         if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8) || (units[i].nstates & ~(0xFF | MIC_HIP_PRED_GRAD))) return MIC_ERR_ARGS;
     }
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)n, s->stream));
+    if ((rc = s->prepare_hist(n))) return rc;
     s->timer.reset(s->stream);
     mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
-    HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->n_last = n;
     return MIC_OK;
 }
@@ -376,9 +376,9 @@ int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, 
     u.nstates = (uint16_t)flavour; u.mode = 1; u.no_fallback = 1; u.req_tl = (uint32_t)table_log;
     s->fill_workspace(u, 0);
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4, s->stream));
+    if ((rc = s->prepare_hist(1))) return rc;
     mic_launch_encode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
-    HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->n_last = 1;
     uint64_t offs[2]; int32_t st = 0, ns = 0; const uint8_t *d_blobs = nullptr;
     if ((rc = session_encode_finish(s, &d_blobs, offs, &st, &ns))) return rc;

@@ -1170,6 +1170,15 @@ __global__ void __launch_bounds__(1024) k_scan_lens(const MicUnit *units, int n,
     }
 }
 
+// The histogram slab goes back to zero behind the chain (the session keeps it zero between calls instead of clearing 256 KiB per unit
+// in front of every one: 17 GB for a 32768^2 slide's 65 535 planes): everything below the tokeniser's bound, or all of it.
+__global__ void __launch_bounds__(256) k_enc_hist_clean(MicUnit *units) {
+    MicUnit &u = units[blockIdx.x];
+    const uint32_t hi = (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u;
+    uint4 *h = (uint4 *)u.hist;                                           // (256 KiB-aligned slab)
+    for (uint32_t i = threadIdx.x; i < (hi + 3) / 4; i += 256) h[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
@@ -1217,6 +1226,10 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     }
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
+    if (variant != 100) {
+        if (t) t->mark("k_enc_hist_clean");
+        hipLaunchKernelGGL(k_enc_hist_clean, dim3(n), dim3(256), 0, stream, d_units);
+    }
     if (t) t->mark("end");
 }
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t) {

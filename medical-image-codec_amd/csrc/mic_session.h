@@ -74,6 +74,21 @@ struct mic_hip_session {
     std::vector<uint64_t> h_off;
     int n_last = 0;
     int variant = 0;                        // kernel generation selector (0 = default)
+    // The per-unit 65536-bin histograms are ZERO between calls: the encode chain leaves them so (k_enc_hist_clean re-zeroes what a
+    // unit's tokeniser counted), and nothing else writes them.  hist_zero_units = leading unit slabs known to be zero (0 after a
+    // reallocation, after the serial kernel generation, after a failed launch).
+    const void *hist_zero_ptr = nullptr; size_t hist_zero_units = 0;
+    int prepare_hist(int n) {
+        if (hist.p != hist_zero_ptr) { hist_zero_ptr = hist.p; hist_zero_units = 0; }
+        if (variant == 100) hist_zero_units = 0;
+        if ((size_t)n > hist_zero_units) {
+            HIP_TRY(hipMemsetAsync((char *)hist.p + kSym * 4 * hist_zero_units, 0, kSym * 4 * ((size_t)n - hist_zero_units), stream));
+            hist_zero_units = (size_t)n;
+        }
+        if (variant == 100) hist_zero_units = 0;                          // (that generation does not clean up behind itself)
+        return MIC_OK;
+    }
+    void hist_unknown() { hist_zero_units = 0; }
     MicTimer timer;
     std::vector<std::string> t_names; std::vector<float> t_ms;
     size_t tok_stride = 0, blob_stride = 0, seg_stride = 0, sym_stride = 0, flag_stride = 0;

@@ -596,8 +596,9 @@ __global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
         dec_tables_body<int16_t, uint16_t>(u, norm16, (uint16_t *)(s_raw + TB_OFF_FIRST), (uint16_t *)(s_raw + TB_OFF_CUM),
                                            (uint16_t *)(s_raw + TB_OFF_VISIT), bitmap, wprefix, big, s_tmp, symbol_len, tl, flavour);
     } else {
-        // HBM scratch: cumul[] first visits, hist[] cum_all, state_tab[] (u32, first half used as u16) visit sequence
-        dec_tables_body<int32_t, uint32_t>(u, u.norm, (uint32_t *)u.cumul, (uint32_t *)u.hist, (uint16_t *)u.state_tab,
+        // HBM scratch: cumul[] first visits, tt_find[] cum_all (not hist[]: the encode side keeps that slab zero between calls),
+        // state_tab[] (u32, first half used as u16) visit sequence
+        dec_tables_body<int32_t, uint32_t>(u, u.norm, (uint32_t *)u.cumul, (uint32_t *)u.tt_find, (uint16_t *)u.state_tab,
                                            bitmap, wprefix, big, s_tmp, symbol_len, tl, flavour);
     }
 }

@@ -88,7 +88,7 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
         else { u.mode = 2; u.nsym = (uint32_t)npx; u.max_value = 0; }
     }
     HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nframes, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nframes, s->stream));
+    if ((rc = s->prepare_hist(nframes))) return rc;
     if (nframes > 1) {
         const unsigned bx = (unsigned)std::min<size_t>((npx + 255) / 256, 1024);
         hipLaunchKernelGGL(k_tmp_residual, dim3(bx, (unsigned)(nframes - 1)), dim3(256), 0, s->stream,
@@ -97,7 +97,7 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
     }
     s->timer.reset(s->stream);
     mic_launch_encode((MicUnit *)s->units.p, nframes, s->stream, s->variant, nullptr);
-    HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->n_last = nframes;
     std::vector<uint64_t> offs((size_t)nframes + 1);
     std::vector<int32_t> st((size_t)nframes), ns((size_t)nframes);

@@ -748,7 +748,7 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
         s->fill_workspace(u, i);
     }
     if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
-    if (hipMemsetAsync(s->hist.p, 0, kSym * 4 * (size_t)nf, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    if ((rc = s->prepare_hist(nf))) return done(rc);
     s->timer.mark("k_wv_symbols");
     {
         const WvDims d = wv_dims(rows, cols, applied);
@@ -758,7 +758,7 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
         hipLaunchKernelGGL(k_wv_symbols, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, (const int32_t *)A, d);   // frames with wide coefficients
     }
     mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer);
-    if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
+    if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return done(MIC_ERR_DEVICE); }
     s->n_last = nf;
     std::vector<uint64_t> offs((size_t)nf + 1); std::vector<int32_t> ns((size_t)nf); const uint8_t *d_blobs = nullptr;
     st.assign((size_t)nf, 0);
