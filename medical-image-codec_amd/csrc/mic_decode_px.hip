@@ -25,6 +25,7 @@
 #define PX_K 8                                    // pixels per thread per wavefront step (in-work-group fallback)
 #define PR_K 64                                   // pixels per lane per step in k_dec_predict: one 128-byte line per row and step
 #define PR_DW (PR_K / 2)
+#define PR_NARROW 1008                            // frames up to this many columns take 16-pixel groups (row buffer: 2 KiB per unit)
 #define PR_MAX_W 32768                            // its row buffer is 2 bytes per column of LDS
 struct __attribute__((packed, aligned(2))) PxVec { uint16_t v[PX_K]; };
 
@@ -418,10 +419,11 @@ typedef pr_v2 PrD __attribute__((aligned(2)));
 typedef uint32_t PrS __attribute__((aligned(2)));
 typedef __attribute__((address_space(1))) uint16_t *pr_gu16;
 
-// cnt (1..PR_K, wave-uniform) pixels of a group, packed two per dword
-__device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[PR_DW], int cnt) {
+// cnt (1..K, wave-uniform) pixels of a group, packed two per dword
+template <int K>
+__device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[K / 2], int cnt) {
 #pragma unroll
-    for (int q = 0; q < PR_K / 8; q++) {
+    for (int q = 0; q < K / 8; q++) {
         const int j = 4 * q;
         pr_gu16 o = dst + 8 * q;
         if (cnt >= 8 * q + 8) {
@@ -444,8 +446,13 @@ __device__ __forceinline__ void pr_store_cnt(pr_gu16 dst, const uint32_t (&d)[PR
     }
 }
 
+#pragma push_macro("PR_K")
+#pragma push_macro("PR_DW")
+#undef PR_K
+#undef PR_DW
+template <int K>
 struct PrSlot {
-    uint32_t d[PR_DW];    // PR_K symbols
+    uint32_t d[K / 2];    // K symbols
     uint32_t w0, w1, w2;  // flag words around the group (funnel-shifted at use: consuming them at fetch time would
                           // make the fetch wait for its own loads)
     int32_t g, y;         // group and row; g < 0 or act == 0: nothing to do
@@ -456,8 +463,12 @@ struct PrSlot {
 // WIDE names the row-buffer class of the launch (a distinct instantiation has its own line in a kernel trace).
 // The ordinary class runs four units per group, one wave each with its own row buffer: a group's waves land on the four
 // SIMDs by construction, whereas single-wave groups pile up unevenly and the younger wave of a crowded SIMD starves.
-template <int WIDE>
+// K = pixels per lane and step.  A lane owns a row and trails the row above by one group, so a band of 64 rows keeps a lane busy
+// (columns / K) steps out of every max(columns / K, 64): 64-pixel groups (one 128-byte line per row and step) suit wide strips, frames
+// of a few hundred columns (MIC3 planes, CT slices) take 16-pixel groups -- at 256 columns 25 % of the steps are work instead of 6 %.
+template <int WIDE, int K>
 __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units, int n_units, int w_lo, int w_hi, uint32_t rb_dwords) {
+    constexpr int PR_K = K, PR_DW = K / 2;                       // (shadow the file-scope defaults)
     constexpr int WPG = WIDE ? 1 : 4;                            // waves (= units) per group
     const int ui = (int)blockIdx.x * WPG + (int)(threadIdx.x >> 6);
     if (ui >= n_units) return;
@@ -508,7 +519,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
 
     // ---- the pipeline ----
     int32_t cg = -(int32_t)lane, cb = 0;                         // cursor of the NEXT group to fetch
-    auto fetch = [&](PrSlot &s) {
+    auto fetch = [&](PrSlot<K> &s) {
         const int32_t y = (int32_t)lane + 64 * cb;
         s.g = cg; s.y = y;
         s.act = (cg >= 0 && cg < ngrp && cb < nb && y < H) ? 1u : 0u;
@@ -539,7 +550,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
 #pragma unroll
     for (int i = 0; i < PR_DW; i++) last[i] = 0;
     uint32_t left = 0;
-    auto step = [&](const PrSlot &s) {
+    auto step = [&](const PrSlot<K> &s) {
         // top neighbours: lane r-1's previous result; lane 0 takes the row buffer entry of its group
         uint32_t top[PR_DW];
         {
@@ -588,8 +599,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
         }
         if (s.act) {
             const pr_gu16 dst = px + s.p;
-            if (s.g < ngrp - 1 || tail == PR_K) pr_store_cnt(dst, res, PR_K);
-            else pr_store_cnt(dst, res, tail);
+            if (s.g < ngrp - 1 || tail == PR_K) pr_store_cnt<K>(dst, res, PR_K);
+            else pr_store_cnt<K>(dst, res, tail);
             if (lane == 63) {
                 uint4 *rb4 = (uint4 *)(s_rowbuf + s.g * PR_DW);
 #pragma unroll
@@ -599,7 +610,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
 #pragma unroll
         for (int i = 0; i < PR_DW; i++) last[i] = res[i];
     };
-    PrSlot sa, sb, sc;
+    PrSlot<K> sa, sb, sc;
     fetch(sa); fetch(sb); fetch(sc);
     const int steps = nb * P + 63;
     for (int t = 0; t < steps; t += 3) {
@@ -608,6 +619,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
         step(sc); fetch(sc);
     }
 }
+
+#pragma pop_macro("PR_DW")
+#pragma pop_macro("PR_K")
 
 // ------------------------------------------------------------------------------------------
 // Inverse gradient-adaptive predictor (GradDeltaRleDecompressU16.Decompress, deltagradrlecompressu16.go:70-133) for units with
@@ -725,10 +739,11 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     // row-buffer classes so that ordinary widths keep many waves per CU: a row buffer is 2 bytes per column and unit, four units per
     // group; up to 4032 columns that is 8 KiB per unit and twenty units per CU (a latency-bound kernel: one wave per unit)
     if (t) t->mark("k_dec_predict<0>");
-    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 4096 * 2, stream, d_units, n, 0, 4096 - PR_K, 2048u);
-    hipLaunchKernelGGL(k_dec_predict<0>, dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 4096 - PR_K, 8192 - PR_K, 4096u);
+    hipLaunchKernelGGL((k_dec_predict<0, 16>), dim3((n + 3) / 4), dim3(256), 4 * 1024 * 2, stream, d_units, n, 0, PR_NARROW, 512u);   // narrow frames: 16-pixel groups (8-pixel groups: slower)
+    hipLaunchKernelGGL((k_dec_predict<0, 64>), dim3((n + 3) / 4), dim3(256), 4 * 4096 * 2, stream, d_units, n, PR_NARROW, 4096 - PR_K, 2048u);
+    hipLaunchKernelGGL((k_dec_predict<0, 64>), dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 4096 - PR_K, 8192 - PR_K, 4096u);
     if (t) t->mark("k_dec_predict<wide>");
-    hipLaunchKernelGGL(k_dec_predict<1>, dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
+    hipLaunchKernelGGL((k_dec_predict<1, 64>), dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
     if (any_grad) {
         if (t) t->mark("k_dec_predict_grad");
         static MicPerDeviceOnce once;
