@@ -28,6 +28,10 @@ stack = np.stack([np.roll(img[:64], 3 * k, axis=1) for k in range(9)])
 rc, want = mico.mic2_compress(stack, 4095, False)
 assert rc == 0 and mic.compress_multi_frame(stack, 300, 64, 4095) == want
 assert np.array_equal(np.asarray(mic.decompress_multi_frame(want)).reshape(stack.shape), stack)
+rc, want = mico.mic2_compress(stack, 4095, True)          # temporal: a residual needs the frame before it across sub-batch edges
+assert rc == 0 and mic.compress_multi_frame(stack, 300, 64, 4095, temporal=True) == want
+assert np.array_equal(np.asarray(mic.decompress_multi_frame(want)).reshape(stack.shape), stack)
+assert np.array_equal(np.asarray(mic.decompress_frame(want, 7)).reshape(64, 300), stack[7])
 res = mic.compress_batch([stack[k] for k in range(9)], [4095] * 9, 2)
 for k, (st, blob, used) in enumerate(res):
     rc, w1 = mico.compress_single_frame(stack[k], 4095, 2)
