@@ -465,11 +465,14 @@ __global__ void __launch_bounds__(256) k_wv_symbols_fin(MicUnit *units, WvDims d
 // next header's position is this one's value), and a walk costs a wave some hundreds of cycles per header whatever else the GPU
 // does.  But the list is self-synchronising: a walk started at a token that is no header lands on a true one within a few steps
 // and is the true walk from there.  So the stream is cut into WP_PARTS parts, a wave per part walks from the part's first token
-// (part 0: from the first header) and leaves its records {payload token | run flag, first symbol RELATIVE to the part} in a
-// region of its own; k_rle_walk_fix then hops from part to part -- the true walk enters a part at the exit of the part before,
-// that position is looked up among the part's first 64 records (if it is not there the frame goes to k_wv_expand) -- and
+// (part 0: from the first header; a walk that takes a zero token for a header has proved itself wrong -- no encoder writes a zero
+// count, and zero symbols are common in literal chunks -- and starts over behind it) and leaves its records {payload token | run
+// flag, first symbol RELATIVE to the part} in a region of its own; k_rle_walk_fix then hops from part to part -- the true walk
+// enters a part at the exit of the part before; the true headers the part's own walk has not got are taken from a 64-token window
+// (up to WP_EXTRA of them, else the frame goes to k_wv_expand) until it stands on a position the part has a record of -- and
 // k_rle_walk_compact moves the true records to the front of `seg` with their absolute symbol positions, filling `flags` with
-// the segment that holds every WS_T-th symbol.  Stop and error rules are k_wv_expand's.
+// the segment that holds every WS_T-th symbol.  A zero count that IS on the true walk is the reference's literal chunk of
+// 65536 - midCount (k_wv_expand reads it so): the fix kernel hands such frames over.  Stop and error rules are k_wv_expand's.
 #define WP_PARTS 64
 #define WP_MINLEN 4096u
 #define WP_EXTRA 1024u                             // true headers a part may hold in front of the point where its own walk joins the true one
