@@ -780,6 +780,12 @@ int mic_hip_debug_fetch_hist(mic_hip_session *s, int i, void *dst, size_t bytes)
     HIP_TRY(hipMemcpy(dst, s->h_units[(size_t)i].hist, bytes, hipMemcpyDeviceToHost));
     return MIC_OK;
 }
+// debug probe (not in the public header): the first n u16 of unit i's token slab after a *_finish
+int mic_hip_debug_fetch_tok(mic_hip_session *s, int i, void *dst, size_t n) {
+    if (!s || i < 0 || i >= s->n_last || n > s->h_units[(size_t)i].tok_cap) return MIC_ERR_ARGS;
+    HIP_TRY(hipMemcpy(dst, s->h_units[(size_t)i].tok, n * 2, hipMemcpyDeviceToHost));
+    return MIC_OK;
+}
 int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {
     if (!s) return MIC_ERR_ARGS;
     s->timer.enabled = enabled != 0;

@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_gl(MicUnit *units) {
 template <int N, bool ZB, int TLHI>
 static void launch_tans_lds_class(MicUnit *d_units, int n, hipStream_t stream) {
     static MicPerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB, TLHI>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    once.run([] { (void)hipFuncSetAttribute((const void *)k_dec_tans_lds<N, ZB, TLHI>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024); });
     hipLaunchKernelGGL((k_dec_tans_lds<N, ZB, TLHI>), dim3(n), dim3(64), (2u << TLHI) + TD_EXTRA, stream, d_units);
 }
 template <int N, bool ZB>
@@ -992,14 +992,14 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         mic_launch_dec_tans_ls(d_units, n, d_cls + MIC_CLS_HEAD, d_cls, stream, t);
     } else if (variant != 100) {
         static MicPerDeviceOnce once;
-        if (once.first()) {
+        once.run([] {
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
             (void)hipFuncSetAttribute((const void *)k_dec_tans_duo<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
-        }
+        });
         const unsigned nw = (unsigned)((n + 2 * T2_WAVES - 1) / (2 * T2_WAVES));
         if (t) t->mark("k_dec_tans_duo<2,false>");
         hipLaunchKernelGGL((k_dec_tans_duo<2, false>), dim3(nw), dim3(64 * T2_WAVES), T2_LDS, stream, d_units, n);

@@ -669,7 +669,7 @@ static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const in
     constexpr int cls = (TL <= 12 ? 4 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
     constexpr int per = LsGeom<TL>::WAVES * LsGeom<TL>::SPW;
     static MicPerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, LsGeom<TL>::LDS);
+    once.run([] { (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, LsGeom<TL>::LDS); });
     const unsigned groups = (unsigned)((n + per - 1) / per);
     hipLaunchKernelGGL((k_dec_tans_ls<N, ZB, TL>), dim3(groups), dim3(64 * LsGeom<TL>::WAVES), LsGeom<TL>::LDS, stream, d_units,
                        d_list + (size_t)cls * (size_t)n, d_count + cls);

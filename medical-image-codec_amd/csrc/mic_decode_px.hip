@@ -747,7 +747,7 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     if (any_grad) {
         if (t) t->mark("k_dec_predict_grad");
         static MicPerDeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_predict_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (PR_MAX_W + 2 * PG_Q) * 2);
+        once.run([] { (void)hipFuncSetAttribute((const void *)k_dec_predict_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (PR_MAX_W + 2 * PG_Q) * 2); });
         hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), 8192 * 2, stream, d_units, 0, 8192 - 2 * PG_Q);
         hipLaunchKernelGGL(k_dec_predict_grad, dim3(n), dim3(64), (PR_MAX_W + 2 * PG_Q) * 2, stream, d_units, 8192 - 2 * PG_Q, PR_MAX_W);
     }

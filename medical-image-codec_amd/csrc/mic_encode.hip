@@ -139,12 +139,12 @@ __global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
 // 14-symbol neighbourhood is one bit mask and "in a same-run", "run start", "stretch start",
 // "run end" are shifts and ANDs of it; run / stretch indices modulo c advance incrementally from
 // one multiply-high reduction per thread and tile.
-#define TK_THREADS 512              // two groups per CU (128 VGPRs each): one group's barriers overlap the other's work
+#define TK_THREADS 512              // three groups per CU (<= 80 VGPRs each): one group's barriers overlap the others' work
 #define TK_WAVES 8
-#define TK_PPT 4
-#define TK_SPT 8
+#define TK_PPT 8                    // pixels per thread and tile
+#define TK_SPT 8                    // window positions per thread
 #define TK_WIN (TK_THREADS * TK_SPT)
-#define TK_HWIN 8192               // histogram window in LDS (with two symbol windows: two groups per CU)
+#define TK_HWIN 8192               // histogram window in LDS
 
 // Wave-wide inclusive scans on the DPP network (row_shr 1/2/4/8, then row_bcast 15 and 31); lanes
 // without a source read the identity 0, so the same shape serves add and max.
@@ -178,29 +178,45 @@ __device__ __forceinline__ void tk_block16_max(const uint32_t *s, uint32_t wave,
     excl = w ? __builtin_amdgcn_readlane(x, w - 1) : 0u;
 }
 
-typedef uint32_t tk_v2 __attribute__((ext_vector_type(2)));
-typedef tk_v2 TkD __attribute__((aligned(2)));                 // 4 pixels, 2-byte aligned
+typedef uint32_t tk_v4 __attribute__((ext_vector_type(4)));
+typedef tk_v4 TkQ __attribute__((aligned(2)));                 // 8 pixels / tokens, 2-byte aligned
+// two u16 per dword on the packed VALU (v_pk_add_u16, v_pk_sub_i16, v_pk_lshrrev_b16, v_pk_min_u16)
+typedef unsigned short tk_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tk_us2 tk_u(uint32_t x) { return __builtin_bit_cast(tk_us2, x); }
+__device__ __forceinline__ uint32_t tk_w(tk_us2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t tk_pk_add(uint32_t a, uint32_t b) { return tk_w(tk_u(a) + tk_u(b)); }
+__device__ __forceinline__ uint32_t tk_pk_sub(uint32_t a, uint32_t b) { return tk_w(tk_u(a) - tk_u(b)); }
+__device__ __forceinline__ uint32_t tk_pk_shr1(uint32_t a) { return tk_w(tk_u(a) >> (tk_us2)(1)); }
+__device__ __forceinline__ uint32_t tk_pk_min(uint32_t a, uint32_t b) { return tk_w(__builtin_elementwise_min(tk_u(a), tk_u(b))); }
+__device__ __forceinline__ uint32_t tk_half(const uint32_t (&w)[4], int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu); }
 
 // SRC 0: frame units (mode 0) -- symbols are the Delta(avg) residuals of the pixels, stream = [delim][RLE(maxValue, symbols)].
 // SRC 1: RLE-of-symbols units (mode 2, wavelet / residual paths) -- RleCompressU16.Init(len,1,max).Compress(symbols)
 //        (rlecompressu16.go:85-93): symbols come from u.sym[0..u.nsym), stream = [max][len>>16][len&0xFFFF][RLE(symbols)].
 // PRED (frame units only) 1: the gradient-adaptive predictor of GradDeltaRleCompressU16 (deltagradrlecompressu16.go:26-68) -- the
 //        same stream with mic_grad_predict(W, N, NW, NE) in place of avg(W, N); units with u.pred == 1 (PICA's second encode).
+//
+// A tile is 4096 pixels, eight per thread, addressed LINEARLY: pixel g's left neighbour is g - 1 and its upper one g - W wherever
+// the thread's eight pixels lie -- across a row end too; the one pixel of a thread that starts a row takes its upper neighbour as
+// its left one (avg(t, t) = t).  With every sample below 2^15 the residuals come two per instruction on the packed VALU.  Their
+// symbols (8 per thread; 16 when every pixel is an escape) go to a 4096-symbol LDS window; a tile that holds an escape is walked
+// in two halves, so the window never holds more.  All 512 threads own 8 window positions.
 template <int SRC, int PRED = 0>
-__global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units) {
+__global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (!SRC && u.pred != (uint32_t)PRED) return;
-    __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per tile parity: [0..5] = 6 symbols before the tile, [6..] = new symbols
+    __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per pass parity: [0..5] = 6 symbols before the window, [6..] = new symbols
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16], s_run[16], s_str[16], s_tc[16];   // per-wave partials (unused tail stays 0)
     __shared__ uint32_t s_ovf, s_last[2];
-    // fused histogram of the token stream (fsecompressu16.go:438-462): a 16384-bin LDS window around
+    __shared__ uint32_t s_frun;                                 // run1 as a fast tile leaves it (its last thread knows it)
+    // fused histogram of the token stream (fsecompressu16.go:438-462): an 8192-bin LDS window around
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     __shared__ uint32_t s_tmaxall;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
     if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
-    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last[0] = s_last[1] = 0; s_tmaxall = 0; }
+    if (tid == 0) { u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0; s_ovf = 0; s_last[0] = s_last[1] = 0; s_tmaxall = 0; s_frun = 0; }
     const int depth = mic_len16(u.max_value);
     if (!SRC && (u.w <= 0 || u.h <= 0)) { if (tid == 0) u.status = MICD_ERR_ARGS; return; }
     if (depth < 4) { if (tid == 0) u.status = MICD_ERR_UNSUPPORTED; return; }   // see k_enc_tokens_serial
@@ -209,10 +225,12 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     const uint32_t mid = (1u << (depth - 1)) - 1;          // Len16(delim) == depth
     const uint32_t c = mid - 3;                            // >= 4
     const uint32_t cmagic = (uint32_t)(0x100000000ull / c);
-    auto mod_c = [&](uint32_t a) -> uint32_t {             // a % c: the multiply-high quotient is at most 1 short
-        const uint32_t r = a - __umulhi(a, cmagic) * c;
-        return r >= c ? r - c : r;
+    auto div_c = [&](uint32_t a, uint32_t &rem) -> uint32_t {   // a / c and a % c: the multiply-high quotient is at most 1 short
+        uint32_t qq = __umulhi(a, cmagic), r = a - qq * c;
+        if (r >= c) { r -= c; qq++; }
+        rem = r; return qq;
     };
+    auto mod_c = [&](uint32_t a) -> uint32_t { uint32_t r; (void)div_c(a, r); return r; };
     const uint16_t *in = SRC ? (const uint16_t *)u.sym : u.px_in;
     uint16_t *tok = u.tok;
     const uint32_t cap = u.tok_cap;
@@ -224,6 +242,10 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     uint32_t g0 = SRC ? 0u : 1u;     // symbols generated so far; frames: symbol 0 = maxValue is pre-seeded in the halo
     uint32_t outp = SRC ? 3u : 1u;   // tokens written so far; tok[0] = delimiter / max (rlecompressu16.go:21) [+ length words]
     uint32_t run1 = 0, str1 = 0;     // index+1 of the first symbol of the current run / diff stretch (0 = none)
+    uint32_t par = 0;                // window parity: every pass over a window flips it
+    bool prev_fast = false;          // the pass before took the fast path: run1 is in s_frun
+    uint32_t fast_cool = 0;          // passes to go before a fast tile is tried again (a refused try costs a barrier)
+    const uint32_t thr2 = thr | (thr << 16), lim2 = (2 * thr - 2) | ((2 * thr - 2) << 16);
     const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
     uint32_t *ghist = u.hist;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
@@ -247,29 +269,32 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         }
     }
     __syncthreads();
-    // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile)
-    struct TkFetch { tk_v2 cv, tv; uint32_t lft, tl, tr, x, y; bool row4; };
+    // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile).
+    // kind 1: the eight pixels, the eight above them and the one to the left came as vectors (all eight have an upper neighbour, or
+    // none has: row 0); kind 2: the thread reads its pixels one by one (the unit's tail, the step from row 0 to row 1, W < 8)
+    struct TkFetch { tk_v4 cv, tv; uint32_t lft, tl, tr, x, y, kind; };
     const uint32_t tile_dy = TP / W, tile_dx = TP - tile_dy * W;   // a tile further on: tile_dy rows and tile_dx columns
     uint32_t ny = (tid * TK_PPT) / W, nx = tid * TK_PPT - ny * W;  // position of this thread's first pixel in the next tile to fetch
     auto fetch = [&](uint32_t tile) -> TkFetch {
-        TkFetch f; f.cv = tk_v2{0u, 0u}; f.tv = tk_v2{0u, 0u}; f.lft = 0; f.tl = 0; f.tr = 0; f.x = 0; f.y = 0; f.row4 = false;
+        TkFetch f; f.cv = tk_v4{0u, 0u, 0u, 0u}; f.tv = tk_v4{0u, 0u, 0u, 0u}; f.lft = 0; f.tl = 0; f.tr = 0; f.x = 0; f.y = 0; f.kind = 0;
         const uint32_t gb = tile * TP + tid * TK_PPT;
         if (tile >= ntiles || gb >= npx) return f;
         if (SRC) {
-            if (gb + TK_PPT <= npx) { f.cv = *(const TkD *)(in + gb); f.row4 = true; }
+            if (gb + TK_PPT <= npx) { f.cv = *(const TkQ *)(in + gb); f.kind = 1; } else f.kind = 2;
             return f;
         }
         f.x = nx; f.y = ny;                                     // tiles are fetched in order: the position advances by a tile
         nx += tile_dx; ny += tile_dy;
         if (nx >= W) { nx -= W; ny++; }
-        f.row4 = f.x + TK_PPT <= W;                             // the 4 pixels share a row
-        if (f.row4) {
-            f.cv = *(const TkD *)(in + gb);
-            if (f.y > 0) f.tv = *(const TkD *)(in + gb - W);
-            if (f.x > 0) f.lft = in[gb - 1];
-            if (PRED && f.y > 0) {                                  // NW of the first pixel, NE of the last (NE = NW at the right edge)
-                if (f.x > 0) f.tl = in[gb - W - 1];
-                f.tr = (f.x + TK_PPT < W) ? (uint32_t)in[gb - W + TK_PPT] : (f.tv.y & 0xFFFFu);
+        f.kind = 2;
+        if (gb + TK_PPT <= npx && W >= TK_PPT && (gb >= W || gb + TK_PPT <= W)) {
+            f.kind = 1;
+            f.cv = *(const TkQ *)(in + gb);
+            if (gb >= W) f.tv = *(const TkQ *)(in + gb - W);
+            if (gb > 0) f.lft = in[gb - 1];
+            if (PRED && gb >= W) {                                  // NW of the first pixel, NE of the last
+                if (gb > W) f.tl = in[gb - W - 1];
+                f.tr = in[gb - W + TK_PPT];
             }
         }
         return f;
@@ -278,48 +303,80 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
     MIC_STAMP_BEGIN();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
-        uint16_t *xs = xs2[tile & 1], *xs_next = xs2[(tile & 1) ^ 1];
         // ---- A: delta symbols of this tile's pixels (deltarlecompressu16.go:31-61) ----------
         uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0; int esc = 0;
+        bool pk_ok = false; uint32_t pk[4] = { 0u, 0u, 0u, 0u };   // the thread's eight symbols as four packed dwords (the usual case)
         const uint32_t gbase = tile * TP + tid * TK_PPT;
         const TkFetch f = nxt;
         nxt = fetch(tile + 1);
         if (!flush && gbase < npx) {
-            const uint32_t cur[TK_PPT] = { f.cv.x & 0xFFFFu, f.cv.x >> 16, f.cv.y & 0xFFFFu, f.cv.y >> 16 };
+            const uint32_t cw[4] = { f.cv.x, f.cv.y, f.cv.z, f.cv.w };
             if (SRC) {
+                if (f.kind == 1) { pk_ok = true; pk[0] = cw[0]; pk[1] = cw[1]; pk[2] = cw[2]; pk[3] = cw[3]; cnt = TK_PPT; }
+                else
 #pragma unroll
-                for (int k = 0; k < TK_PPT; k++) if (gbase + k < npx) ls[cnt++] = f.row4 ? cur[k] : (uint32_t)in[gbase + k];
-            } else {
-                const uint32_t top[TK_PPT] = { f.tv.x & 0xFFFFu, f.tv.x >> 16, f.tv.y & 0xFFFFu, f.tv.y >> 16 };
+                for (int k = 0; k < TK_PPT; k++) if (gbase + k < npx) ls[cnt++] = (uint32_t)in[gbase + k];
+            } else if (f.kind == 1) {
+                const uint32_t tw[4] = { f.tv.x, f.tv.y, f.tv.z, f.tv.w };
                 const uint32_t x = f.x, y = f.y;
-                const bool row4 = f.row4;
+                if (!PRED && y > 0 && ((cw[0] | cw[1] | cw[2] | cw[3] | tw[0] | tw[1] | tw[2] | tw[3] | f.lft) & 0x80008000u) == 0) {
+                    // prev = floor((l + t) / 2) = (l & t) + ((l ^ t) >> 1), symbol = thr + cur - prev, two pixels per instruction.  The
+                    // 16-bit differences are exact below 2^15, and |diff| < thr <=> 1 <= symbol <= 2 thr - 1 (a wrapped negative
+                    // lands above 2^15 + thr).  A thread with an escape takes the per-pixel code below.
+                    uint32_t lw[4] = { __builtin_amdgcn_alignbit(cw[0], f.lft << 16, 16), __builtin_amdgcn_alignbit(cw[1], cw[0], 16),
+                                       __builtin_amdgcn_alignbit(cw[2], cw[1], 16), __builtin_amdgcn_alignbit(cw[3], cw[2], 16) };
+                    if (x == 0 || x + TK_PPT > W) {                    // pixel kz starts a row: its prediction is the pixel above it
+                        const uint32_t kz = x ? W - x : 0u;
+                        const uint32_t hm = (kz & 1u) ? 0xFFFF0000u : 0x0000FFFFu;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if ((kz >> 1) == (uint32_t)j) lw[j] = (lw[j] & ~hm) | (tw[j] & hm);
+                    }
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t pv = tk_pk_add(lw[j] & tw[j], tk_pk_shr1(lw[j] ^ tw[j]));
+                        pk[j] = tk_pk_add(tk_pk_sub(cw[j], pv), thr2);
+                        const uint32_t e = tk_pk_sub(pk[j], 0x00010001u);
+                        bad |= tk_pk_min(e, lim2) ^ e;
+                    }
+                    if (!bad) { pk_ok = true; cnt = TK_PPT; }
+                }
+                if (!pk_ok)
+#pragma unroll
+                for (int k = 0; k < TK_PPT; k++) {
+                    uint32_t xk = x + k, yk = y;
+                    if (xk >= W) { xk -= W; yk++; }
+                    const uint32_t val = tk_half(cw, k), l = k ? tk_half(cw, k ? k - 1 : 0) : f.lft, t = tk_half(tw, k);
+                    int32_t prev;
+                    if (xk > 0 && yk > 0) {
+                        if (PRED) {
+                            const int32_t nw = (int32_t)(k ? tk_half(tw, k ? k - 1 : 0) : f.tl);
+                            const int32_t ne = (xk + 1 < W) ? (int32_t)(k + 1 < TK_PPT ? tk_half(tw, k + 1 < TK_PPT ? k + 1 : 0) : f.tr) : nw;
+                            prev = mic_grad_predict((int32_t)l, (int32_t)t, nw, ne);
+                        } else prev = (int32_t)((l + t) >> 1);
+                    }
+                    else if (xk > 0) prev = (int32_t)l;
+                    else prev = (int32_t)t;                              // 0 on row 0 (kind 1 there: no upper row was read)
+                    const int32_t diff = (int32_t)val - prev;
+                    const uint32_t ad = (uint32_t)(diff < 0 ? -diff : diff) & 0xFFFF;
+                    if (ad >= thr) { ls[cnt++] = delim; ls[cnt++] = val; esc = 1; }
+                    else ls[cnt++] = (uint32_t)((int32_t)thr + diff) & 0xFFFF;
+                }
+            } else {
 #pragma unroll
                 for (int k = 0; k < TK_PPT; k++) {
                     const uint32_t g = gbase + k;
                     if (g >= npx) break;
-                    uint32_t val; int32_t prev;
-                    if (row4) {
-                        val = cur[k];
-                        const uint32_t l = k ? cur[k - 1] : f.lft;
-                        if (x + k > 0 && y > 0) {
-                            if (PRED) prev = mic_grad_predict((int32_t)l, (int32_t)top[k], (int32_t)(k ? top[k - 1] : f.tl),
-                                                              (int32_t)(k + 1 < TK_PPT ? top[k + 1] : f.tr));
-                            else prev = (int32_t)((l + top[k]) >> 1);
-                        }
-                        else if (x + k > 0) prev = (int32_t)l;
-                        else prev = (int32_t)top[k];                        // 0 on row 0
-                    } else if (PRED) {
-                        const uint32_t yy = g / W, xx = g - yy * W;
-                        prev = mic_grad_predict_at(in, (int)W, (int)xx, (int)yy);
-                        val = in[g];
-                    } else {
-                        const uint32_t yy = g / W, xx = g - yy * W;
+                    const uint32_t yy = g / W, xx = g - yy * W;
+                    int32_t prev;
+                    if (PRED) prev = mic_grad_predict_at(in, (int)W, (int)xx, (int)yy);
+                    else {
                         prev = 0;
                         if (xx > 0) prev = in[g - 1];
                         if (yy > 0) prev += in[g - W];
                         if (xx > 0 && yy > 0) prev >>= 1;
-                        val = in[g];
                     }
+                    const uint32_t val = in[g];
                     const int32_t diff = (int32_t)val - prev;
                     const uint32_t ad = (uint32_t)(diff < 0 ? -diff : diff) & 0xFFFF;
                     if (ad >= thr) { ls[cnt++] = delim; ls[cnt++] = val; esc = 1; }
@@ -327,22 +384,40 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
                 }
             }
         }
-        uint32_t off, n;
-        if (__syncthreads_or(esc)) {                            // rare: an escape doubles its pixel, offsets need a scan
-            const uint32_t incl = tk_wave_incl_add(cnt, lane);
+        // The symbols go to the window as if the tile held no escape (a thread's offset is then its own); the barrier that collects the
+        // escape flags orders these stores too, and a tile with an escape stores again, half by half, behind a scan.
+        {
+            uint16_t *xs = xs2[par];
+            if (pk_ok) { uint32_t *d = (uint32_t *)(xs + 6 + tid * TK_PPT); d[0] = pk[0]; d[1] = pk[1]; d[2] = pk[2]; d[3] = pk[3]; }
+            else if (!esc) {
+#pragma unroll
+                for (int k = 0; k < TK_PPT; k++) if ((uint32_t)k < cnt) xs[6 + tid * TK_PPT + k] = (uint16_t)ls[k];
+            }
+        }
+        const bool esc_tile = __syncthreads_or(esc) != 0;
+        if (prev_fast) { run1 = s_frun; prev_fast = false; }    // written behind the fast tile's decision barrier, ordered by this one
+        if (esc_tile && pk_ok) {
+#pragma unroll
+            for (int k = 0; k < TK_PPT; k++) ls[k] = tk_half(pk, k);
+        }
+        const uint32_t npass = esc_tile ? 2u : 1u;
+        for (uint32_t pass = 0; pass < npass; pass++) {
+        uint16_t *xs = xs2[par], *xs_next = xs2[par ^ 1];
+        uint32_t n;
+        if (esc_tile) {                                         // rare: an escape doubles its pixel, offsets need a scan (per half tile)
+            const bool mine = (tid >> 8) == pass;
+            const uint32_t mycnt = mine ? cnt : 0u;
+            const uint32_t incl = tk_wave_incl_add(mycnt, lane);
             if (lane == 63) s_cnt[wave] = incl;
             __syncthreads();
             uint32_t woff;
             tk_block16_add(s_cnt, wave, woff, n);
-            off = woff + incl - cnt;
-        } else {
-            off = tid * TK_PPT;
-            n = flush ? 0u : min(TP, npx - tile * TP);
-        }
+            const uint32_t off = woff + incl - mycnt;
 #pragma unroll
-        for (int k = 0; k < 2 * TK_PPT; k++) if ((uint32_t)k < cnt) xs[6 + off + k] = (uint16_t)ls[k];
-        __syncthreads();
-        if (tid < 6) xs_next[tid] = xs[n + tid];                // halo of the next tile (its window is idle until then)
+            for (int k = 0; k < 2 * TK_PPT; k++) if ((uint32_t)k < mycnt) xs[6 + off + k] = (uint16_t)ls[k];
+            __syncthreads();
+        } else n = flush ? 0u : min(TP, npx - tile * TP);
+        if (tid < 6) xs_next[tid] = xs[n + tid];                // halo of the next window (idle until then)
         const uint32_t g1 = g0 + n;
         MIC_STAMP_AT(u, 0);
         // window position p <-> symbol i = g0 - 3 + p <-> xs[p + 3];  i3 = i + 3 = g0 + p keeps the arithmetic unsigned
@@ -383,7 +458,7 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         const uint32_t SAME = (SS >> 1) & V;
         const uint32_t RS = ~(EM >> 2) & V;                     // first symbol of a maximal run
         uint32_t PREV = SS & 0xFFu;                             // bit q: isSame of symbol q-1
-        if (p0 == 0) PREV = (PREV & ~1u) | s_last[(tile & 1) ^ 1];   // the symbol before the window was classified last tile
+        if (p0 == 0) PREV = (PREV & ~1u) | s_last[par ^ 1];     // the symbol before the window was classified last pass
         {
             const int32_t q0 = 3 - (int32_t)(g0 + p0);          // position of symbol 0, if it is one of these 8
             if (q0 >= 0 && q0 < 8) PREV |= 1u << q0;            // i == 0 opens a stretch whatever came "before"
@@ -393,14 +468,26 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         const uint32_t ibase = g0 + p0 - 2;                     // (i + 1) of position 0
         const uint32_t my_run = RS ? ibase + (31 - __clz(RS)) : 0u;
         const uint32_t my_str = STS ? ibase + (31 - __clz(STS)) : 0u;
-        // exclusive max-scan of the thread-latest starts (positions grow with the thread index)
-        const uint32_t run_incl = tk_wave_incl_max(my_run, lane), str_incl = tk_wave_incl_max(my_str, lane);
-        if (lane == 63) { s_run[wave] = run_incl; s_str[wave] = str_incl; }
-        uint32_t run_in = __shfl_up(run_incl, 1), str_in = __shfl_up(str_incl, 1);
-        if (lane == 0) { run_in = 0; str_in = 0; }
-        __syncthreads();
-        uint32_t run_tot, str_tot;
-        {
+        // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start: eight literals of one stretch.  The
+        // only thing that can happen is a chunk boundary: position bq opens a chunk (one more token: its header slot) and position
+        // bq - 1 closes one (it patches the header c tokens back).
+        const bool lit8 = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && c >= 16;
+        // ---- fast tile: every thread of a full tile is lit8 and the stretch is under way.  Token positions are closed-form then: no
+        // scans, one barrier (the vote) instead of two; the only carried state that moves is the start of the last run, and the tile's
+        // last thread knows it.  A refused vote costs its barrier, so it is tried again only after a while.
+        bool tile_fast = false;
+        if (!flush && !esc_tile && n == TP && c >= 16 && g0 >= 6 && str1 != 0 && g0 >= str1 + 3) {
+            if (fast_cool) fast_cool--;
+            else { tile_fast = !__syncthreads_or(lit8 ? 0 : 1); fast_cool = tile_fast ? 0u : 12u; }
+        }
+        uint32_t run_in = 0, str_in = str1, run_tot = run1, str_tot = str1;
+        if (!tile_fast) {
+            // exclusive max-scan of the thread-latest starts (positions grow with the thread index)
+            const uint32_t run_incl = tk_wave_incl_max(my_run, lane), str_incl = tk_wave_incl_max(my_str, lane);
+            if (lane == 63) { s_run[wave] = run_incl; s_str[wave] = str_incl; }
+            run_in = __shfl_up(run_incl, 1); str_in = __shfl_up(str_incl, 1);
+            if (lane == 0) { run_in = 0; str_in = 0; }
+            __syncthreads();
             uint32_t ra, sa;
             tk_block16_max(s_run, wave, ra, run_tot);
             tk_block16_max(s_str, wave, sa, str_tot);
@@ -411,56 +498,67 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         // ---- C: tokens owned by each position ---------------------------------------------------
         // k = 1-based index in the run, j = 1-based index in the stretch; rk = (k-3) % c, sj = (j-1) % c
         uint32_t k_in = 0, j_in = 0, rk_in = 0, sj_in = 0;     // state in front of position 0 (D replays the recurrence)
-        uint32_t bq = 0xFFFFu;                                  // fast path: position that opens a literal chunk (>= 8: none here)
-        uint32_t tsum = 0;
-        bool fast = false;                                      // 8 plain literals inside one chunk: the usual case in noisy data
+        uint32_t bq = 0xFFFFu;                                  // lit8: position that opens a literal chunk (>= 8: none here)
+        uint32_t tsum = 0, jq = 0;
         const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
         if (V) {
             // state of the symbol in front of position 0 (index i0 - 1 = ibase - 2)
             uint32_t k = (run_in != 0 && ibase >= run_in + 1) ? ibase - run_in : 0u;       // (i0-1) + 2 - run_in
             uint32_t j = (str_in != 0 && ibase >= str_in + 1) ? ibase - str_in : 0u;
-            uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
-            uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
-            k_in = k; j_in = j; rk_in = rk; sj_in = sj;
-            // no same-run symbol among these 8 or right behind them (SS bits 1..9), no stretch start: eight literals of
-            // one stretch.  The only thing that can happen is a chunk boundary: position bq = c - 1 - sj opens a chunk
-            // (one more token: its header slot) and position bq - 1 closes one (it patches the header c tokens back).
-            fast = !flush && V == 0xFFu && (SS & 0x3FEu) == 0 && STS == 0 && c >= 16;
-            if (fast) { bq = c - 1 - sj; tsum = TK_SPT + (bq < TK_SPT ? 1u : 0u); }
-            else
+            if (lit8) {
+                uint32_t jr;                                     // j >= 1 here (the stretch is under way)
+                jq = div_c(j, jr);
+                bq = jr ? c - jr : 0u;                           // position q opens a chunk <=> (j + q) % c == 0
+                jq += jr ? 1u : 0u;                              // ceil(j / c): chunks of the stretch opened in front of position 0, + 1
+                tsum = TK_SPT + (bq < TK_SPT ? 1u : 0u);
+            } else {
+                uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
+                uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
+                k_in = k; j_in = j; rk_in = rk; sj_in = sj;
 #pragma unroll
-            for (int q = 0; q < TK_SPT; q++) {
-                const uint32_t bit = 1u << q;
-                if (V & bit) {
-                    if (RS & bit) k = 1; else k++;
-                    if (k == 3) rk = 0; else if (k > 3) { rk++; if (rk == c) rk = 0; }
-                    if (STS & bit) { j = 1; sj = 0; } else { j++; sj++; if (sj == c) sj = 0; }
-                    uint32_t t;
-                    if (SAME & bit) {
-                        t = ((k > 3 && rk == 0) ? 2u : 0u) + ((LAST & bit) ? 2u : 0u);
-                    } else {
-                        const bool ex2 = !flush || (g0 + p0 + q) < ex2_lim;
-                        t = ((j == 1) || (sj == 0 && ex2)) ? 2u : 1u;
+                for (int q = 0; q < TK_SPT; q++) {
+                    const uint32_t bit = 1u << q;
+                    if (V & bit) {
+                        if (RS & bit) k = 1; else k++;
+                        if (k == 3) rk = 0; else if (k > 3) { rk++; if (rk == c) rk = 0; }
+                        if (STS & bit) { j = 1; sj = 0; } else { j++; sj++; if (sj == c) sj = 0; }
+                        uint32_t t;
+                        if (SAME & bit) {
+                            t = ((k > 3 && rk == 0) ? 2u : 0u) + ((LAST & bit) ? 2u : 0u);
+                        } else {
+                            const bool ex2 = !flush || (g0 + p0 + q) < ex2_lim;
+                            t = ((j == 1) || (sj == 0 && ex2)) ? 2u : 1u;
+                        }
+                        tsum += t;
                     }
-                    tsum += t;
                 }
             }
         }
 #ifdef MIC_STAMP
-        if (!__all(fast || !V) && lane == 0) atomicAdd(&u.dbg[15], 1u);   // wave-tiles that take the general path
+        if (!__all(lit8 || !V) && lane == 0) atomicAdd(&u.dbg[15], 1u);   // wave-tiles that take the general path
+        if (tile_fast && tid == 0) atomicAdd(&u.dbg[14], 1u);             // fast tiles
 #endif
-        const uint32_t tincl = tk_wave_incl_add(tsum, lane);
-        if (lane == 63) s_tc[wave] = tincl;
-        __syncthreads();
-        uint32_t toff, ttot;
-        tk_block16_add(s_tc, wave, toff, ttot);
+        uint32_t pos, ttot;
+        if (tile_fast) {
+            // chunks opened in front of position p0 = ceil((J0 + p0) / c) - ceil(J0 / c), J0 = the stretch index of the symbol in front
+            // of the tile (thread 0's j); the tile's total likewise
+            uint32_t r0, rT;
+            const uint32_t c0 = div_c(g0 - 2 - str1, r0) + (r0 ? 1u : 0u);
+            const uint32_t cT = div_c(g0 - 2 - str1 + TP, rT) + (rT ? 1u : 0u);
+            pos = outp + p0 + (jq - c0);
+            ttot = TP + (cT - c0);
+        } else {
+            const uint32_t tincl = tk_wave_incl_add(tsum, lane);
+            if (lane == 63) s_tc[wave] = tincl;
+            __syncthreads();
+            uint32_t toff;
+            tk_block16_add(s_tc, wave, toff, ttot);
+            pos = outp + toff + tincl - tsum;
+        }
         MIC_STAMP_AT(u, 2);
         // ---- D: write ----------------------------------------------------------------------------
-        if (fast) {
-            const uint32_t pos = outp + toff + tincl - tsum;
+        if (lit8) {
             if (pos + TK_SPT + 1 <= cap) {
-                typedef uint32_t tk_v4 __attribute__((ext_vector_type(4)));
-                typedef tk_v4 TkQ __attribute__((aligned(2)));
                 if (bq >= TK_SPT) {
                     tk_v4 o;
                     o.x = v[3] | (v[4] << 16); o.y = v[5] | (v[6] << 16); o.z = v[7] | (v[8] << 16); o.w = v[9] | (v[10] << 16);
@@ -477,19 +575,14 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
 #pragma unroll
                 for (int q = 0; q < TK_SPT; q++) dmax = max(dmax, v[q + 3] - hlo);
                 if (dmax < TK_HWIN) {
-#ifdef TK_ABL_NOHIST
-                    atomicAdd(&s_hist[v[3] - hlo], 8u);
-#else
 #pragma unroll
                     for (int q = 0; q < TK_SPT; q++) atomicAdd(&s_hist[v[q + 3] - hlo], 1u);
-#endif
                 } else {
 #pragma unroll
                     for (int q = 0; q < TK_SPT; q++) count_tok(v[q + 3]);
                 }
             } else s_ovf = 1;
         } else if (V) {
-            uint32_t pos = outp + toff + tincl - tsum;
             bool ovf = false;
             uint32_t k = k_in, j = j_in, rk = rk_in, sj = sj_in;
 #pragma unroll
@@ -537,18 +630,23 @@ __global__ void __launch_bounds__(TK_THREADS, 4) k_enc_tokens_wg(MicUnit *units)
         }
         MIC_STAMP_AT(u, 3);
         // ---- E: carry --------------------------------------------------------------------------------
-        // (the barriers of the next tile order these LDS words; both are double-buffered by tile parity)
+        // (the barriers of the next pass order these LDS words; both are double-buffered by window parity)
         outp += ttot;
-        run1 = run_tot; str1 = str_tot;
+        if (tile_fast) {
+            if (tid == TK_THREADS - 1) s_frun = my_run;        // (RS != 0 there: eight symbols without a run of three)
+            prev_fast = true;
+        } else { run1 = run_tot; str1 = str_tot; }
         {
             // isSame of the last processed symbol, or the previous value when none was processed
             const bool processed = nwin > 0 && g0 + nwin - 1 >= 3;
             const uint32_t pl = processed ? nwin - 1 : 0u;
-            if (processed) { if (tid == pl / TK_SPT) s_last[tile & 1] = (SAME >> (pl % TK_SPT)) & 1u; }
-            else if (tid == 0) s_last[tile & 1] = s_last[(tile & 1) ^ 1];
+            if (processed) { if (tid == pl / TK_SPT) s_last[par] = (SAME >> (pl % TK_SPT)) & 1u; }
+            else if (tid == 0) s_last[par] = s_last[par ^ 1];
         }
         g0 = g1;
+        par ^= 1u;
         MIC_STAMP_AT(u, 4);
+        }   // pass
     }
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
@@ -1208,12 +1306,12 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     }
     if (variant != 100) {
         static MicPerDeviceOnce once;
-        if (once.first()) {
+        once.run([] {
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        }
+        });
         if (t) t->mark("k_enc_tans_wg<13>");
         hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
         if (t) t->mark("k_enc_tans_wg<13, one wave>");

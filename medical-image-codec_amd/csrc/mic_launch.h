@@ -2,21 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <vector>
 #include "mic_dev.h"
 
-// Kernel attributes (opt-in dynamic LDS) are per device, and launches come from any thread: true exactly when the calling thread's
-// current device has not run `setup` yet.  A second thread may see true for the same device while the first is still at it -- the
-// attribute calls are idempotent, so that is harmless.
+// Kernel attributes (opt-in dynamic LDS) are per device, and launches come from any thread: run(setup) calls `setup` once per device
+// (the calling thread's current one) and returns only after it has completed there, whichever thread ran it -- the device's bit is
+// published AFTER the attribute calls, under the mutex, so no thread can launch a > 64 KiB-LDS kernel on a device whose opt-in is
+// still on its way.  The fast path is one acquire load.
 struct MicPerDeviceOnce {
     std::atomic<uint64_t> mask{0};
-    bool first() {
+    std::mutex mu;
+    template <class F> void run(F &&setup) {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess) return true;
+        if (hipGetDevice(&d) != hipSuccess) { setup(); return; }
         const uint64_t bit = 1ull << (d & 63);
-        if (mask.load(std::memory_order_acquire) & bit) return false;
-        mask.fetch_or(bit, std::memory_order_acq_rel);
-        return true;
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (mask.load(std::memory_order_relaxed) & bit) return;
+        setup();
+        mask.fetch_or(bit, std::memory_order_release);
     }
 };
 

@@ -35,15 +35,17 @@ int check_device(int device);      // MIC_OK when `device` exists and is gfx950 
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    uint64_t gen = 0;                       // bumped by every (re)allocation: the contents are undefined from then on, whatever the address
     int reserve(size_t bytes) {
         if (bytes <= cap) return MIC_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 4096;
+        gen++;
         HIP_TRY(hipMalloc(&p, want));
         cap = want;
         return MIC_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; gen++; }
 };
 
 constexpr size_t kSym = 65536;
@@ -76,10 +78,11 @@ struct mic_hip_session {
     int variant = 0;                        // kernel generation selector (0 = default)
     // The per-unit 65536-bin histograms are ZERO between calls: the encode chain leaves them so (k_enc_hist_clean re-zeroes what a
     // unit's tokeniser counted), and nothing else writes them.  hist_zero_units = leading unit slabs known to be zero (0 after a
-    // reallocation, after the serial kernel generation, after a failed launch).
-    const void *hist_zero_ptr = nullptr; size_t hist_zero_units = 0;
+    // reallocation, after the serial kernel generation, after a failed launch).  The invariant is tied to the ALLOCATION (DevBuf::gen),
+    // not to the address: hipFree + a larger hipMalloc may hand the same address back with undefined contents.
+    uint64_t hist_zero_gen = ~0ull; size_t hist_zero_units = 0;
     int prepare_hist(int n) {
-        if (hist.p != hist_zero_ptr) { hist_zero_ptr = hist.p; hist_zero_units = 0; }
+        if (hist.gen != hist_zero_gen) { hist_zero_gen = hist.gen; hist_zero_units = 0; }
         if (variant == 100) hist_zero_units = 0;
         if ((size_t)n > hist_zero_units) {
             HIP_TRY(hipMemsetAsync((char *)hist.p + kSym * 4 * hist_zero_units, 0, kSym * 4 * ((size_t)n - hist_zero_units), stream));

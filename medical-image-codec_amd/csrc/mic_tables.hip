@@ -605,12 +605,12 @@ __global__ void __launch_bounds__(TP_THREADS) k_dec_tables_wg(MicUnit *units) {
 
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream) {
     static MicPerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void *)k_enc_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
+    once.run([] { (void)hipFuncSetAttribute((const void *)k_enc_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); });
     hipLaunchKernelGGL(k_enc_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
 }
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream) {
     static MicPerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void *)k_dec_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
+    once.run([] { (void)hipFuncSetAttribute((const void *)k_dec_tables_wg, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES); });
     hipLaunchKernelGGL(k_dec_parse<false>, dim3(n), dim3(64), 0, stream, d_units);
     hipLaunchKernelGGL(k_dec_parse<true>, dim3(n), dim3(64), 0, stream, d_units);
     hipLaunchKernelGGL(k_dec_tables_wg, dim3(n), dim3(TP_THREADS), TB_LDS_BYTES, stream, d_units);
