@@ -884,12 +884,15 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 // TTL: the per-symbol records (symbolTT / rANS freq+bias) were copied to LDS (alphabets up to TE_TT_SYMS);
 // otherwise every coding step gathers them from HBM.
 template <int N, bool RANS, bool TTL, int T>
-__device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, const int32_t *s_ttfind,
+__device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                           uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
     const uint16_t *src = u.tok;
-    const uint32_t *tt_nb = TTL ? s_ttnb : u.tt_nb; const int32_t *tt_find = TTL ? s_ttfind : u.tt_find;
+    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
+    // the coding record of a symbol: {deltaNbBits, deltaFindState} (rANS: {freq | k0 << 20, bias}) -- one 8-byte LDS read when the
+    // alphabet's records were copied there, two gathers from HBM otherwise
+    auto rec = [&](uint32_t sy) -> uint2 { return TTL ? s_tt[sy] : make_uint2(tt_nb[sy], (uint32_t)tt_find[sy]); };
     uint16_t *stv = u.sym;
     const uint32_t hdr_len = u.hdr_len;
     uint8_t *bits_base = u.blob + 6 + hdr_len;
@@ -906,20 +909,17 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     // tt_nb = freq | k0 << 20, tt_find = bias; both emit (state & mask(nb), nb) and both forget
     // the old state down to one of `freq` values, which is what makes the walks merge.
     auto step = [&](uint32_t state, uint32_t sy, uint32_t &nb_out) -> uint32_t {
+        const uint2 r = rec(sy);
         if (RANS) {
-            const uint32_t e = tt_nb[sy], freq = e & 0xFFFFF, k0 = e >> 20;
+            const uint32_t e = r.x, freq = e & 0xFFFFF, k0 = e >> 20;
             const uint32_t k = k0 - ((state < (freq << k0)) ? 1u : 0u);
             nb_out = k;
-            return size + (uint32_t)tt_find[sy] + ((state >> k) - freq);
+            return size + r.y + ((state >> k) - freq);
         } else {
-            const uint32_t nb = (state + tt_nb[sy]) >> 16;
+            const uint32_t nb = (state + r.x) >> 16;
             nb_out = nb;
-            return size + s_stab[(int32_t)(state >> nb) + tt_find[sy]];
+            return size + s_stab[(int32_t)(state >> nb) + (int32_t)r.y];
         }
-    };
-    auto nbits = [&](uint32_t state, uint32_t sy) -> uint32_t {
-        if (RANS) { const uint32_t e = tt_nb[sy], freq = e & 0xFFFFF, k0 = e >> 20; return k0 - ((state < (freq << k0)) ? 1u : 0u); }
-        return (state + tt_nb[sy]) >> 16;
     };
     MIC_STAMP_BEGIN();
     // Per group of TE_RGRP blocks (128 tokens) the walk leaves a record in HBM: the N states after the group
@@ -950,13 +950,23 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
     auto walk_block = [&](uint32_t base, uint32_t (&stw)[N]) -> uint32_t {
         const TeBlk tk = te_load(src + base);
         uint32_t bits = 0;
+        if (base + TE_BLK <= n) {                                   // every block but the stream's last: no per-token bound
 #pragma unroll
-        for (int j = TE_BLK - 1; j >= 0; j--) {
-            if (base + (uint32_t)j < n) {
+            for (int j = TE_BLK - 1; j >= 0; j--) {
                 const int k = j & (N - 1);
                 uint32_t nb;
                 stw[k] = step(stw[k], te_get(tk, j), nb);
                 bits += nb;
+            }
+        } else {
+#pragma unroll
+            for (int j = TE_BLK - 1; j >= 0; j--) {
+                if (base + (uint32_t)j < n) {
+                    const int k = j & (N - 1);
+                    uint32_t nb;
+                    stw[k] = step(stw[k], te_get(tk, j), nb);
+                    bits += nb;
+                }
             }
         }
         return bits;
@@ -1101,25 +1111,35 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint32_t *s_ttnb, 
         const uint32_t lastown = (nblk + per - 1) / per;   // threads 0 .. lastown-1 own tokens; s_E[T-1] was overwritten for the trailer
 #pragma unroll
         for (int k = 0; k < N; k++) stp[k] = (tid > 0 && tid < lastown) ? (uint32_t)s_E[tid - 1][k] + size : size;
+        // Four tokens (<= 64 bits) are gathered branch-free before they meet the accumulator: the test "does a 64-bit unit fill up"
+        // is a divergent branch that some lane takes at almost every token, so it is made once per four of them.
         for (uint32_t b = b_hi; b > b_lo; b--) {
             const uint32_t base = (b - 1) * TE_BLK;
             const TeBlk tk = te_load(src + base);
+            const bool whole = base + TE_BLK <= n;
 #pragma unroll
-            for (int j = TE_BLK - 1; j >= 0; j--) {
-                if (base + (uint32_t)j < n) {
-                    const int k = j & (N - 1);
-                    const uint32_t stt = stp[k];
-                    uint32_t nb;
-                    stp[k] = step(stt, te_get(tk, j), nb);
-                    const uint32_t bv = stt & ((1u << nb) - 1u);             // nb <= 16
-                    acc |= (uint64_t)bv << filled;
-                    const uint32_t nf = filled + nb;
-                    if (nf >= 64) {
-                        emit(acc);
-                        acc = (uint64_t)(bv >> (64u - filled));              // what did not fit (filled >= 48 here: a shift by 1..16)
-                        filled = nf - 64;
-                    } else filled = nf;
+            for (int j4 = TE_BLK / 4 - 1; j4 >= 0; j4--) {
+                uint64_t t4 = 0; uint32_t f4 = 0;
+#pragma unroll
+                for (int jj = 3; jj >= 0; jj--) {
+                    const int j = j4 * 4 + jj;
+                    if (whole || base + (uint32_t)j < n) {
+                        const int k = j & (N - 1);
+                        const uint32_t stt = stp[k];
+                        uint32_t nb;
+                        stp[k] = step(stt, te_get(tk, j), nb);
+                        const uint32_t bv = __builtin_amdgcn_ubfe(stt, 0u, nb);   // nb <= 16
+                        t4 |= (uint64_t)bv << f4;                                // f4 <= 48 here
+                        f4 += nb;
+                    }
                 }
+                acc |= t4 << filled;                                             // filled < 64
+                const uint32_t nf = filled + f4;
+                if (nf >= 64) {
+                    emit(acc);
+                    acc = filled ? (t4 >> (64u - filled)) : 0ull;                // what did not fit
+                    filled = nf - 64;
+                } else filled = nf;
             }
         }
     }
@@ -1165,7 +1185,7 @@ __device__ __forceinline__ int te_small_class(const MicUnit &u) {
 template <int TLHI, int T, int TTS>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI); threads; LDS coding records
 __global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
     constexpr uint32_t tl_lo = (TLHI <= 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
-    extern __shared__ uint16_t s_stab[];
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_stab[];
     __shared__ uint16_t s_E[T][8];
     __shared__ uint32_t s_scan[(T / 64) + 2];
     MicUnit &u = units[blockIdx.x];
@@ -1178,10 +1198,9 @@ __global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
     if (u.nstates != 108) for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
-    uint32_t *s_ttnb = (uint32_t *)(s_stab + (1u << TLHI));
-    int32_t *s_ttfind = (int32_t *)(s_ttnb + TTS);
+    uint2 *s_tt = (uint2 *)(s_stab + (1u << TLHI));                              // TTS coding records, 8 bytes each
     const bool ttl = TLHI <= 15 && u.symbol_len <= TTS;
-    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += T) { s_ttnb[i] = u.tt_nb[i]; s_ttfind[i] = u.tt_find[i]; }
+    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += T) s_tt[i] = make_uint2(u.tt_nb[i], (uint32_t)u.tt_find[i]);
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
     const bool rans = u.nstates == 108;                                          // rans8state.go: 8 lanes, magic FF 08
@@ -1194,17 +1213,17 @@ __global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
             if (TLHI <= 15 && ttl) {
-                if (rans) te_encode<8, true, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, true, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             } else {
-                if (rans) te_encode<8, true, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, false, T>(u, s_stab, s_ttnb, s_ttfind, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             }
         }
         __syncthreads();
