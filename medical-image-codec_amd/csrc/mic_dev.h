@@ -79,6 +79,14 @@ struct MicUnit {
     uint32_t dbg[16];         // MIC_STAMP builds: shader-clock ticks per kernel phase (tools/stamp_*.py)
 };
 
+// A pointer read out of a MicUnit is "generic" to the compiler, and generic accesses are flat_load / flat_store: those count on
+// lgkmcnt as well as on vmcnt, so every s_waitcnt lgkmcnt(0) -- there is one in front of every work-group barrier -- waits for the
+// HBM loads and stores in flight (a prefetch issued before a barrier is no prefetch any more).  mic_g() states what every
+// workspace pointer is: global memory (global_load / global_store: vmcnt only).
+#define MIC_GLOBAL __attribute__((address_space(1)))
+template <class T> using mic_gp = MIC_GLOBAL T *;
+template <class T> __device__ __forceinline__ mic_gp<T> mic_g(T *p) { return (mic_gp<T>)p; }
+
 // Phase stamps for diagnostic builds (EXTRA_FLAGS=-DMIC_STAMP); they compile to nothing otherwise.
 #ifdef MIC_STAMP
 #define MIC_STAMP_BEGIN() uint64_t _mic_t0 = __builtin_amdgcn_s_memtime()

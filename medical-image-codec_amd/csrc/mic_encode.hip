@@ -231,8 +231,9 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         rem = r; return qq;
     };
     auto mod_c = [&](uint32_t a) -> uint32_t { uint32_t r; (void)div_c(a, r); return r; };
-    const uint16_t *in = SRC ? (const uint16_t *)u.sym : u.px_in;
-    uint16_t *tok = u.tok;
+    const mic_gp<const uint16_t> in = mic_g(SRC ? (const uint16_t *)u.sym : u.px_in);   // (global_load / global_store: the prefetch
+    const mic_gp<uint16_t> tok = mic_g(u.tok);                                          //  below has to survive the barriers)
+    typedef MIC_GLOBAL const TkQ *GTkQc; typedef MIC_GLOBAL TkQ *GTkQ;
     const uint32_t cap = u.tok_cap;
     const uint32_t W = SRC ? 1u : (uint32_t)u.w;
     const uint32_t npx = SRC ? u.nsym : W * (uint32_t)u.h;
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     uint32_t fast_cool = 0;          // passes to go before a fast tile is tried again (a refused try costs a barrier)
     const uint32_t thr2 = thr | (thr << 16), lim2 = (2 * thr - 2) | ((2 * thr - 2) << 16);
     const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
-    uint32_t *ghist = u.hist;
+    const mic_gp<uint32_t> ghist = mic_g(u.hist);
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
     for (uint32_t i = tid; i < 2 * (TK_WIN + 16); i += TK_THREADS) (&xs2[0][0])[i] = 0;
     if (tid < 16) { s_cnt[tid] = 0; s_run[tid] = 0; s_str[tid] = 0; s_tc[tid] = 0; }
@@ -255,7 +256,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     uint32_t tmax = 0;                                      // largest token counted outside the LDS window
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
-        if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u); else { atomicAdd(&ghist[v], 1u); tmax = max(tmax, v); }
+        if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u);
+        else { (void)__hip_atomic_fetch_add(&ghist[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tmax = max(tmax, v); }
     };
     if (tid == 0) {
         if (SRC) {
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         const uint32_t gb = tile * TP + tid * TK_PPT;
         if (tile >= ntiles || gb >= npx) return f;
         if (SRC) {
-            if (gb + TK_PPT <= npx) { f.cv = *(const TkQ *)(in + gb); f.kind = 1; } else f.kind = 2;
+            if (gb + TK_PPT <= npx) { f.cv = *(GTkQc)(in + gb); f.kind = 1; } else f.kind = 2;
             return f;
         }
         f.x = nx; f.y = ny;                                     // tiles are fetched in order: the position advances by a tile
@@ -289,8 +291,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         f.kind = 2;
         if (gb + TK_PPT <= npx && W >= TK_PPT && (gb >= W || gb + TK_PPT <= W)) {
             f.kind = 1;
-            f.cv = *(const TkQ *)(in + gb);
-            if (gb >= W) f.tv = *(const TkQ *)(in + gb - W);
+            f.cv = *(GTkQc)(in + gb);
+            if (gb >= W) f.tv = *(GTkQc)(in + gb - W);
             if (gb > 0) f.lft = in[gb - 1];
             if (PRED && gb >= W) {                                  // NW of the first pixel, NE of the last
                 if (gb > W) f.tl = in[gb - W - 1];
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
                     if (g >= npx) break;
                     const uint32_t yy = g / W, xx = g - yy * W;
                     int32_t prev;
-                    if (PRED) prev = mic_grad_predict_at(in, (int)W, (int)xx, (int)yy);
+                    if (PRED) prev = mic_grad_predict_at((const uint16_t *)in, (int)W, (int)xx, (int)yy);
                     else {
                         prev = 0;
                         if (xx > 0) prev = in[g - 1];
@@ -536,7 +538,6 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         }
 #ifdef MIC_STAMP
         if (!__all(lit8 || !V) && lane == 0) atomicAdd(&u.dbg[15], 1u);   // wave-tiles that take the general path
-        if (tile_fast && tid == 0) atomicAdd(&u.dbg[14], 1u);             // fast tiles
 #endif
         uint32_t pos, ttot;
         if (tile_fast) {
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
                 if (bq >= TK_SPT) {
                     tk_v4 o;
                     o.x = v[3] | (v[4] << 16); o.y = v[5] | (v[6] << 16); o.z = v[7] | (v[8] << 16); o.w = v[9] | (v[10] << 16);
-                    *(TkQ *)(tok + pos) = o;
+                    *(GTkQ)(tok + pos) = o;
                 } else {                                         // header slot at pos + bq, patched by whoever closes that chunk
 #pragma unroll
                     for (int q = 0; q < TK_SPT; q++) tok[pos + q + ((uint32_t)q >= bq ? 1u : 0u)] = (uint16_t)v[q + 3];
@@ -650,7 +651,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     }
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
-    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t vv = s_hist[i]; if (vv) atomicAdd(&ghist[hlo + i], vv); }
+    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t vv = s_hist[i]; if (vv) (void)__hip_atomic_fetch_add(&ghist[hlo + i], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     // what k_enc_tables_wg has to scan of the 65536 bins: the window and whatever was counted outside it
     tmax = tk_wave_incl_max(tmax, lane);
     if (lane == 63 && tmax) atomicMax(&s_tmaxall, tmax);
@@ -860,13 +861,11 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 
 // One block of 32 tokens / 32 recorded states as four 16-byte vectors.
 struct TeBlk { uint4 v[4]; };
-__device__ __forceinline__ TeBlk te_load(const uint16_t *p) {
-    TeBlk b; const uint4 *q = (const uint4 *)p;
-    b.v[0] = q[0]; b.v[1] = q[1]; b.v[2] = q[2]; b.v[3] = q[3];
+__device__ __forceinline__ TeBlk te_load(mic_gp<const uint16_t> p) {
+    TeBlk b; const mic_gp<const tk_v4> q = (mic_gp<const tk_v4>)p;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const tk_v4 x = q[i]; b.v[i] = make_uint4(x.x, x.y, x.z, x.w); }
     return b;
-}
-__device__ __forceinline__ void te_store(uint16_t *p, const TeBlk &b) {
-    uint4 *q = (uint4 *)p; q[0] = b.v[0]; q[1] = b.v[1]; q[2] = b.v[2]; q[3] = b.v[3];
 }
 __device__ __forceinline__ uint32_t te_get(const TeBlk &b, int j) {   // j compile-time after unrolling
     const uint4 &v = b.v[j >> 3];
@@ -888,16 +887,16 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                           uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
-    const uint16_t *src = u.tok;
-    const uint32_t *tt_nb = u.tt_nb; const int32_t *tt_find = u.tt_find;
+    const mic_gp<const uint16_t> src = mic_g((const uint16_t *)u.tok);
+    const mic_gp<const uint32_t> tt_nb = mic_g((const uint32_t *)u.tt_nb); const mic_gp<const int32_t> tt_find = mic_g((const int32_t *)u.tt_find);
     // the coding record of a symbol: {deltaNbBits, deltaFindState} (rANS: {freq | k0 << 20, bias}) -- one 8-byte LDS read when the
     // alphabet's records were copied there, two gathers from HBM otherwise
     auto rec = [&](uint32_t sy) -> uint2 { return TTL ? s_tt[sy] : make_uint2(tt_nb[sy], (uint32_t)tt_find[sy]); };
-    uint16_t *stv = u.sym;
+    const mic_gp<uint16_t> stv = mic_g(u.sym);
     const uint32_t hdr_len = u.hdr_len;
-    uint8_t *bits_base = u.blob + 6 + hdr_len;
+    const mic_gp<uint8_t> bits_base = mic_g(u.blob) + 6 + hdr_len;
     const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 15);          // the bit grid starts at a 16-byte boundary: the pack pass stores pairs of 64-bit units
-    uint32_t *words = (uint32_t *)(bits_base - lead);
+    const mic_gp<uint32_t> words = (mic_gp<uint32_t>)(bits_base - lead);
     const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
     const uint32_t nblk = (n + TE_BLK - 1) / TE_BLK;
     const uint32_t per = (nblk + T - 1) / T;
@@ -928,7 +927,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     // twice and states never stored.  Record slot = tid * gper + group index inside the thread's range.
     constexpr uint32_t RWP = (N == 1) ? 2u : 2u * N;       // u16 per record: N states, the bit count, padding
     const uint32_t gper = (per + TE_RGRP - 1) / TE_RGRP;
-    uint32_t *const rec32 = (uint32_t *)stv + (size_t)tid * gper * (RWP / 2);
+    const mic_gp<uint32_t> rec32 = (mic_gp<uint32_t>)stv + (size_t)tid * gper * (RWP / 2);
     auto rec_store = [&](uint32_t g, const uint32_t (&stw)[N], uint32_t bits) {
         uint32_t w[RWP / 2];
 #pragma unroll
@@ -1090,7 +1089,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     // its width or its neighbours (1.74 GB of output as dword stores = 435 M x 32 bytes = 13.9 GB of WRITE_SIZE, measured in two
     // orders of the same stores; as 64-bit stores 8.3 GB and 6.4 -> 5.2 ms), so the pass makes a quarter as many.  A unit is stored by
     // the thread owning its first bit; the threads that only reach into it OR their bits in after a barrier.
-    unsigned long long *const words64 = (unsigned long long *)words;
+    const mic_gp<unsigned long long> words64 = (mic_gp<unsigned long long>)words;
     const uint32_t first_q = (uint32_t)(gstart >> 6);
     const bool own_first = (gstart & 63) == 0;
     uint32_t q = first_q;
@@ -1101,7 +1100,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     auto emit = [&](uint64_t v) {                                          // unit q is complete (or the thread's last, partial one)
         if (q == first_q && !own_first) { lead_val = v; have_lead = true; }
         else if (q & 1u) {
-            if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(te_u2 *)(words64 + (q - 1)) = pr; have_pend = false; }
+            if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(mic_gp<te_u2>)(words64 + (q - 1)) = pr; have_pend = false; }
             else words64[q] = v;
         } else { pend = v; have_pend = true; }
         q++;
@@ -1147,7 +1146,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
     __threadfence_block();
     __syncthreads();
-    if (have_lead && lead_val) atomicOr(&words64[first_q], (unsigned long long)lead_val);
+    if (have_lead && lead_val) (void)__hip_atomic_fetch_or(&words64[first_q], (unsigned long long)lead_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
@@ -1197,10 +1196,13 @@ __global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
-    if (u.nstates != 108) for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(u.state_tab[i] - size);
+    if (u.nstates != 108) { const mic_gp<const uint32_t> gst = mic_g((const uint32_t *)u.state_tab); for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(gst[i] - size); }
     uint2 *s_tt = (uint2 *)(s_stab + (1u << TLHI));                              // TTS coding records, 8 bytes each
     const bool ttl = TLHI <= 15 && u.symbol_len <= TTS;
-    if (ttl) for (uint32_t i = tid; i < u.symbol_len; i += T) s_tt[i] = make_uint2(u.tt_nb[i], (uint32_t)u.tt_find[i]);
+    if (ttl) {
+        const mic_gp<const uint32_t> gnb = mic_g((const uint32_t *)u.tt_nb); const mic_gp<const int32_t> gfi = mic_g((const int32_t *)u.tt_find);
+        for (uint32_t i = tid; i < u.symbol_len; i += T) s_tt[i] = make_uint2(gnb[i], (uint32_t)gfi[i]);
+    }
     __syncthreads();
     const uint32_t hdr_len = u.hdr_len;
     const bool rans = u.nstates == 108;                                          // rans8state.go: 8 lanes, magic FF 08
@@ -1253,14 +1255,14 @@ __global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
 __global__ void __launch_bounds__(256) k_enc_pack(const MicUnit *units, const uint64_t *dst_off, uint8_t *dst) {
     const MicUnit &u = units[blockIdx.y];
     if (u.status != MICD_OK) return;
-    const uint8_t *src = u.blob + (u.nstates_used == 1 ? 6 : 0);
-    uint8_t *d = dst + dst_off[blockIdx.y];
+    const mic_gp<const uint8_t> src = mic_g((const uint8_t *)u.blob) + (u.nstates_used == 1 ? 6 : 0);
+    const mic_gp<uint8_t> d = mic_g(dst) + dst_off[blockIdx.y];
     // 16 bytes per thread and step; neither side is aligned (gfx950 runs vector memory in unaligned mode)
     typedef uint32_t pk_v4 __attribute__((ext_vector_type(4)));
     typedef pk_v4 PkQ __attribute__((aligned(1)));
     const uint32_t len = u.blob_len, nvec = len / 16;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x)
-        *(PkQ *)(d + (size_t)i * 16) = *(const PkQ *)(src + (size_t)i * 16);
+        *(mic_gp<PkQ>)(d + (size_t)i * 16) = *(mic_gp<const PkQ>)(src + (size_t)i * 16);
     if (blockIdx.x == 0 && threadIdx.x < (len & 15u)) d[nvec * 16 + threadIdx.x] = src[nvec * 16 + threadIdx.x];
 }
 
