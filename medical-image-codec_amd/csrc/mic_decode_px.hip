@@ -624,6 +624,251 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256) k_dec_predict(MicUnit *units,
 #pragma pop_macro("PR_K")
 
 // ------------------------------------------------------------------------------------------
+// The same wavefront for wide frames, with the memory traffic taken off the computing wave: TWO waves per unit.
+//
+// k_dec_predict above gives every lane a row, so each of its vector loads and stores touches 64 different cache lines (one per
+// lane), a line is consumed over eight instructions, and every conditional store makes the compiler wait for ALL outstanding
+// memory (s_waitcnt vmcnt(0): the counter is in order, loads and stores together) -- its prefetch never runs ahead.  Here
+//   * wave M (memory) moves TILES: the 64 groups of a step -- lane r's group t - r, 32 pixels = 64 bytes each, a diagonal of the
+//     band -- come in with four 16-byte loads in which four consecutive lanes cover one group (a quad of lanes = one 64-byte
+//     request), are written to LDS one group per 80-byte line (16 bytes of padding: bank-conflict-free both ways), and the
+//     finished tile of the step before leaves the same way.  Its waits for memory stall nobody else; it also turns the flag words
+//     of a group into the 32 raw bits the computing lane needs;
+//   * wave C (compute) reads its group from LDS (four 16-byte reads), runs the recurrence, writes the result in place.  It issues
+//     no global memory operation inside the loop, so it never waits for one.
+// One barrier per step keeps the two in lockstep: C works on tile t while M stores tile t - 1 and fetches tile t + 2.
+#define P2_K 32
+#define P2_DW 16
+#define P2_LS 20                                   // dwords per LDS line: 16 of data + 4 of padding
+#define P2_TILE (64 * P2_LS)
+__global__ void __launch_bounds__(128) k_dec_predict2(MicUnit *units, int w_lo, int w_hi, uint32_t rb_dwords) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.mode != 0 || u.pred) return;
+    const int W = u.w, H = u.h;
+    if (W <= w_lo || W > w_hi) return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_p2[];   // row buffer | two tiles | two x 64 raw-bit words
+    uint32_t *const s_rowbuf = s_p2;
+    uint32_t *const s_tile = s_p2 + rb_dwords;
+    uint32_t *const s_raw = s_tile + 2 * P2_TILE;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool wave_c = threadIdx.x < 64;
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    const uint32_t thr = u.dec_thr;
+    const pr_gu16 px = (pr_gu16)u.px_out;
+    const __attribute__((address_space(1))) uint32_t *flags = (const __attribute__((address_space(1))) uint32_t *)u.flags;
+    const int ngrp = (W + P2_K - 1) / P2_K;
+    const int P = max(ngrp, 64);
+    const int nb = (H + 63) >> 6;
+    const int steps = nb * P + 63;
+
+    if (wave_c) {
+        // ---- row 0: out[x] = raw ? sym : out[x-1] + sym - thr, out[-1] = 0; a scan of (reset, sum) pairs (as in k_dec_predict) ----
+        uint16_t *row16 = (uint16_t *)s_rowbuf;
+        for (int x = (int)lane; x < ngrp * P2_K; x += 64) row16[x] = (x < W) ? px[x] : (uint16_t)0;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const int cw = (W + 63) >> 6;
+        const int x0 = min(W, (int)lane * cw), x1 = min(W, x0 + cw);
+        uint32_t rs = 0, sum = 0;
+        for (int x = x0; x < x1; x++) {
+            const uint32_t raw = (flags[x >> 5] >> (x & 31)) & 1u, v = row16[x];
+            if (raw) { rs = 1; sum = v; } else sum = (sum + v - thr) & 0xFFFFu;
+        }
+        uint32_t is = sum, ir = rs;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t os = __shfl_up(is, dd), orr = __shfl_up(ir, dd);
+            if (lane >= (uint32_t)dd && !ir) { is = (is + os) & 0xFFFFu; ir = orr; }
+        }
+        uint32_t cur = __shfl_up(is, 1);
+        if (lane == 0) cur = 0;
+        for (int x = x0; x < x1; x++) {
+            const uint32_t raw = (flags[x >> 5] >> (x & 31)) & 1u, v = row16[x];
+            cur = raw ? v : ((cur + v - thr) & 0xFFFFu);
+            row16[x] = (uint16_t)cur;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+
+    // ---- wave M: tile mover -------------------------------------------------------------------------------------------------
+    // lane i handles, for k = 0..3, the 16-byte chunk (i & 3) of line 16 k + (i >> 2), and the raw bits of line i.  A cursor walks
+    // a line's sequence of groups incrementally (group, band, first pixel of the chunk; a line whose rows have run out parks at a
+    // group number that stays negative).  Loads run two tiles ahead of the stores; a chunk goes out of and into the SAME LDS slot
+    // of the same lane (tile t - 1's result out, tile t + 1's pixels in), so the exchange needs no second buffer and no barrier.
+    if (!wave_c) {
+        const uint32_t ch = lane & 3;
+        const uint32_t cmax = ((uint32_t)W - ch * 8 + (P2_K - 1)) / P2_K;      // groups of a row in which this lane's chunk has pixels
+        const uint32_t crem = (uint32_t)W - ch * 8 - (cmax - 1) * P2_K;         // pixels of the chunk in the last of them (>= 1)
+        struct Cur { int32_t cg, cb; uint32_t p; };
+        constexpr int32_t PARKED = -(1 << 30);
+        auto cur_init = [&](Cur &c, int line, int tile, uint32_t coff) {        // cursor of `line` at tile `tile` <= line (tile - line <= 0)
+            c.cg = (line < H) ? tile - line : PARKED; c.cb = 0;
+            c.p = (uint32_t)line * (uint32_t)W + coff + (uint32_t)((tile - line) * P2_K);
+        };
+        auto cur_next = [&](Cur &c, int line, uint32_t coff) {
+            c.cg++; c.p += P2_K;
+            if (c.cg == P) {
+                c.cb++;
+                const int y = line + 64 * c.cb;
+                c.cg = (c.cb < nb && y < H) ? 0 : PARKED;
+                c.p = (uint32_t)y * (uint32_t)W + coff;
+            }
+        };
+        Cur lc[4], sc[4], fc;                                                   // load cursors (two tiles ahead), store cursors, flag cursor
+#pragma unroll
+        for (int k = 0; k < 4; k++) { cur_init(lc[k], 16 * k + (int)(lane >> 2), 0, ch * 8); cur_init(sc[k], 16 * k + (int)(lane >> 2), -1, ch * 8); }
+        cur_init(fc, (int)lane, 0, 0);
+        auto load_tile = [&](pr_v4 (&r)[4], uint32_t &rawbits) {              // the tile under the load cursors; advances them
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[k] = pr_v4{0u, 0u, 0u, 0u};
+                if ((uint32_t)lc[k].cg < cmax) {
+                    const uint32_t p = lc[k].p;
+#if defined(P2_ABL) && (P2_ABL & 2)
+                    r[k] = pr_v4{p, p, p, p};
+#else
+                    if (p + 8 <= npx) r[k] = *(const __attribute__((address_space(1))) PrQ *)(px + p);
+                    else {                                                   // the unit's last pixels: stay inside the buffer
+                        uint32_t e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) e[j] = (p + (uint32_t)j < npx) ? (uint32_t)px[p + j] : 0u;
+                        r[k] = pr_v4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+                    }
+#endif
+                }
+                cur_next(lc[k], 16 * k + (int)(lane >> 2), ch * 8);
+            }
+            rawbits = 0;
+            if ((uint32_t)fc.cg < (uint32_t)ngrp) {
+                const uint32_t fp = fc.p;
+                rawbits = __builtin_amdgcn_alignbit(flags[(fp >> 5) + 1], flags[fp >> 5], fp);   // bit k: pixel p + k is stored raw
+                if (fc.cb == 0 && lane == 0) rawbits = 0xFFFFFFFFu;           // row 0 comes ready-made from the row buffer
+            }
+            cur_next(fc, (int)lane, 0);
+        };
+        // tile `tile`'s pixels into its LDS slots; what the slots held -- the results of tile `tile` - 2, under the store cursors -- to memory
+        auto swap_tile = [&](int tile, const pr_v4 (&r)[4], uint32_t rawbits) {
+            uint32_t *tb = s_tile + (tile & 1) * P2_TILE;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int line = 16 * k + (int)(lane >> 2);
+                uint4 *slot = (uint4 *)(tb + line * P2_LS + ch * 4);
+                const uint4 v = *slot;
+                *slot = make_uint4(r[k].x, r[k].y, r[k].z, r[k].w);
+                if ((uint32_t)sc[k].cg < cmax) {
+                    const pr_gu16 dst = px + sc[k].p;
+                    const uint32_t cnt = ((uint32_t)sc[k].cg == cmax - 1) ? min(8u, crem) : 8u;
+#if !(defined(P2_ABL) && (P2_ABL & 4))
+                    if (cnt == 8) { pr_v4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *(__attribute__((address_space(1))) PrQ *)dst = w; }
+                    else { const uint32_t d[4] = { v.x, v.y, v.z, v.w }; pr_store_cnt<8>(dst, d, (int)cnt); }
+#endif
+                }
+                cur_next(sc[k], line, ch * 8);
+            }
+            s_raw[(tile & 1) * 64 + lane] = rawbits;
+        };
+        pr_v4 ra[4], rb[4]; uint32_t fa, fb;
+        const pr_v4 zero4[4] = { pr_v4{0u, 0u, 0u, 0u}, pr_v4{0u, 0u, 0u, 0u}, pr_v4{0u, 0u, 0u, 0u}, pr_v4{0u, 0u, 0u, 0u} };
+        load_tile(ra, fa);                                                      // tile 0
+        {   // tile 0 goes in without anything coming out (the store cursors stand at tile -1: step 0 takes that)
+            uint32_t *tb = s_tile;
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(uint4 *)(tb + (16 * k + (int)(lane >> 2)) * P2_LS + ch * 4) = make_uint4(ra[k].x, ra[k].y, ra[k].z, ra[k].w);
+            s_raw[lane] = fa;
+        }
+        load_tile(ra, fa);                                                      // tile 1
+        load_tile(rb, fb);                                                      // tile 2
+        __syncthreads();                                                        // tile 0 and row 0 are in place
+        for (int t = 0; t < steps; t += 2) {
+            // step t (even): tile t + 1 sits in ra, tile t + 2 in rb; tile t + 3 goes to ra.  Out goes tile t - 1.
+            swap_tile(t + 1, ra, fa);
+            load_tile(ra, fa);
+            __syncthreads();
+            if (t + 1 >= steps) break;
+            swap_tile(t + 2, rb, fb);
+            load_tile(rb, fb);
+            __syncthreads();
+        }
+        swap_tile(steps + 1, zero4, 0u);                                        // the last tile's results (same slots as tile steps - 1)
+        return;
+    }
+
+    // ---- wave C: the recurrence -------------------------------------------------------------------------------------------------
+    __syncthreads();
+    int32_t cg = -(int32_t)lane, cb = 0;                         // this lane's group and band at the current step
+    uint32_t last[P2_DW];                                        // this lane's previous result = next lane's top
+#pragma unroll
+    for (int i = 0; i < P2_DW; i++) last[i] = 0;
+    uint32_t left = 0;
+    for (int t = 0; t < steps; t++) {
+        uint32_t *tb = s_tile + (t & 1) * P2_TILE + lane * P2_LS;
+        const int32_t y = (int32_t)lane + 64 * cb;
+        const bool act = cg >= 0 && cg < ngrp && cb < nb && y < H;
+        uint32_t d[P2_DW];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint4 v = *(const uint4 *)(tb + 4 * q); d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w; }
+        uint32_t raw = act ? s_raw[(t & 1) * 64 + lane] : 0u;
+        // top neighbours: lane r-1's previous result; lane 0 takes the row buffer entry of its group
+        uint32_t top[P2_DW];
+        {
+            const int32_t gc = min(max(cg, 0), ngrp - 1);
+            const uint4 *rb4 = (const uint4 *)(s_rowbuf + gc * P2_DW);
+            uint32_t lv[P2_DW];
+#pragma unroll
+            for (int i = 0; i < P2_DW; i++) lv[i] = 0;
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint4 v = rb4[q]; lv[4 * q] = v.x; lv[4 * q + 1] = v.y; lv[4 * q + 2] = v.z; lv[4 * q + 3] = v.w; }
+            }
+#pragma unroll
+            for (int i = 0; i < P2_DW; i++) top[i] = __builtin_amdgcn_update_dpp(lv[i], last[i], 0x138, 0xF, 0xF, false);   // wave_shr:1
+        }
+        uint32_t (&res)[P2_DW] = last;                           // (every lane has read its neighbour's `last` by now)
+        if (cg == 0) left = top[0] & 0xFFFFu;                    // column 0: predictor = top ((top+top)>>1)
+#if defined(P2_ABL) && (P2_ABL & 1)
+        if (true) {
+#pragma unroll
+            for (int i = 0; i < P2_DW; i++) res[i] = d[i] + top[i];
+        } else
+#endif
+        if (!__any(raw != 0)) {
+#pragma unroll
+            for (int i = 0; i < P2_DW; i++) {
+                const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
+                const uint32_t c0 = (d[i] & 0xFFFFu) - thr, c1 = (d[i] >> 16) - thr;
+                const uint32_t r0 = (((left + t0) >> 1) + c0) & 0xFFFFu;
+                const uint32_t r1 = (((r0 + t1) >> 1) + c1) & 0xFFFFu;
+                res[i] = r0 | (r1 << 16);
+                left = r1;
+            }
+        } else {
+            const bool row0 = y == 0;
+#pragma unroll
+            for (int i = 0; i < P2_DW; i++) {
+                const uint32_t rw = raw >> (2 * i);                    // bits 0, 1: this dword's pixels
+                const uint32_t src = row0 ? top[i] : d[i];
+                const uint32_t t0 = top[i] & 0xFFFFu, t1 = top[i] >> 16;
+                const uint32_t v0 = src & 0xFFFFu, v1 = src >> 16;
+                const uint32_t r0 = (rw & 1u) ? v0 : ((((left + t0) >> 1) + v0 - thr) & 0xFFFFu);
+                const uint32_t r1 = (rw & 2u) ? v1 : ((((r0 + t1) >> 1) + v1 - thr) & 0xFFFFu);
+                res[i] = r0 | (r1 << 16);
+                left = r1;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) *(uint4 *)(tb + 4 * q) = make_uint4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+            if (lane == 63) {
+                uint4 *rb4 = (uint4 *)(s_rowbuf + cg * P2_DW);
+#pragma unroll
+                for (int q = 0; q < 4; q++) rb4[q] = make_uint4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+            }
+        }
+        if (++cg == P) { cg = 0; cb++; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Inverse gradient-adaptive predictor (GradDeltaRleDecompressU16.Decompress, deltagradrlecompressu16.go:70-133) for units with
 // pred = 1 (PICA strips flagged picaFlagGradPredictor).  Input as for k_dec_predict: px_out holds each pixel's delta symbol (or the
 // raw value where its flag bit is set).  One wave per unit, lane r owns row 64 b + r of band b and lags the row above by one
@@ -740,8 +985,10 @@ void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTi
     // group; up to 4032 columns that is 8 KiB per unit and twenty units per CU (a latency-bound kernel: one wave per unit)
     if (t) t->mark("k_dec_predict<0>");
     hipLaunchKernelGGL((k_dec_predict<0, 16>), dim3((n + 3) / 4), dim3(256), 4 * 1024 * 2, stream, d_units, n, 0, PR_NARROW, 512u);   // narrow frames: 16-pixel groups (8-pixel groups: slower)
-    hipLaunchKernelGGL((k_dec_predict<0, 64>), dim3((n + 3) / 4), dim3(256), 4 * 4096 * 2, stream, d_units, n, PR_NARROW, 4096 - PR_K, 2048u);
-    hipLaunchKernelGGL((k_dec_predict<0, 64>), dim3((n + 3) / 4), dim3(256), 4 * 8192 * 2, stream, d_units, n, 4096 - PR_K, 8192 - PR_K, 4096u);
+    // wide frames: two waves per unit (k_dec_predict2), classes by row-buffer size: 2688 columns = 5.25 KiB + 11 KiB of tiles per unit,
+    // nine units per CU
+    hipLaunchKernelGGL(k_dec_predict2, dim3(n), dim3(128), (1344u + 2 * P2_TILE + 128) * 4, stream, d_units, PR_NARROW, 2688, 1344u);
+    hipLaunchKernelGGL(k_dec_predict2, dim3(n), dim3(128), (4096u + 2 * P2_TILE + 128) * 4, stream, d_units, 2688, 8192 - PR_K, 4096u);
     if (t) t->mark("k_dec_predict<wide>");
     hipLaunchKernelGGL((k_dec_predict<1, 64>), dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
     if (any_grad) {
