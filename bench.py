@@ -279,6 +279,80 @@ def leg_wsi(mic, torch, synth, dev, steps, size=32768):
             "roofline": roofline_block(kmean, tile_rgb_bytes, nbytes)}
 
 
+def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
+    """SURVEY.md §8(d) "Timing", the second figure: host buffers in, host buffers out, through the C ABI's batch entry points
+    (mic_hip_pics_compress_batch / _decompress_batch -- what a cgo caller uses), for ordinary (pageable) numpy buffers and for
+    pinned ones (mic_hip_host_alloc), at B = all frames and B = 1; beside it the box's pinned H2D / D2H copy rates, and the
+    fraction of the PCIe floor (bytes in / H2D rate + bytes out / D2H rate) the call reaches."""
+    B = d_px.shape[0]
+    frame_bytes = W * H * 2
+    host = d_px.cpu().numpy().view(np.uint16).reshape(B, H, W)
+
+    # the link: one 1 GiB pinned buffer each way
+    n = 1 << 30
+    pin = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    dv = torch.empty(n, dtype=torch.uint8, device=dev)
+    rates = {}
+    for name, fn in (("h2d", lambda: dv.copy_(pin, non_blocking=True)), ("d2h", lambda: pin.copy_(dv, non_blocking=True))):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        rates[name] = 3 * n / (time.perf_counter() - t0) / 1e9
+    del pin, dv
+
+    def run(kind):
+        if kind == "pinned":
+            src = mic.host_alloc(B * frame_bytes, np.uint16).reshape(B, H, W)
+            src[...] = host
+            cbuf = mic.host_alloc(B * frame_bytes)
+            back = mic.host_alloc(B * frame_bytes, np.uint16).reshape(B, H, W)
+        else:
+            src = host
+            cbuf = np.empty(B * frame_bytes, dtype=np.uint8)
+            back = np.empty((B, H, W), dtype=np.uint16)
+        imgs = [src[i] for i in range(B)]
+        outs = [cbuf[i * frame_bytes:(i + 1) * frame_bytes] for i in range(B)]
+        pxo = [back[i].reshape(-1) for i in range(B)]
+        best = None
+        for it in range(3):                                     # the first pass pays for the session's workspace
+            t0 = time.perf_counter()
+            res = mic.compress_parallel_strips_batch(imgs, maxv, S, 2, outs=outs)
+            t1 = time.perf_counter()
+            assert all(st == 0 for st, _ in res)
+            files = [b for _, b in res]
+            t2 = time.perf_counter()
+            dec = mic.decompress_parallel_strips_batch(files, [(W, H)] * B, outs=pxo)
+            t3 = time.perf_counter()
+            assert all(st == 0 for st, _ in dec)
+            if it and (best is None or (t1 - t0) + (t3 - t2) < best[0] + best[1]):
+                best = (t1 - t0, t3 - t2)
+        assert np.array_equal(back, host), "end-to-end round trip differs"
+        comp = sum(len(f) for f in files)
+        raw = B * frame_bytes
+        floor_enc = raw / rates["h2d"] / 1e9 + comp / rates["d2h"] / 1e9
+        floor_dec = comp / rates["h2d"] / 1e9 + raw / rates["d2h"] / 1e9
+        # B = 1: one frame, one call each way
+        t0 = time.perf_counter(); (st, one), = mic.compress_parallel_strips_batch(imgs[:1], maxv, S, 2, outs=outs[:1]); t1 = time.perf_counter()
+        (st2, _), = mic.decompress_parallel_strips_batch([one], [(W, H)], outs=pxo[:1]); t2 = time.perf_counter()
+        r = {"encode_GBps": round(raw / best[0] / 1e9, 3), "decode_GBps": round(raw / best[1] / 1e9, 3),
+             "encode_decode_GBps": round(raw / (best[0] + best[1]) / 1e9, 3),
+             "encode_ms": round(best[0] * 1e3, 2), "decode_ms": round(best[1] * 1e3, 2),
+             "pcie_floor_ms": {"encode": round(floor_enc * 1e3, 2), "decode": round(floor_dec * 1e3, 2)},
+             "fraction_of_pcie_floor": {"encode": round(floor_enc / best[0], 3), "decode": round(floor_dec / best[1], 3)},
+             "b1_encode_ms": round((t1 - t0) * 1e3, 2), "b1_decode_ms": round((t2 - t1) * 1e3, 2)}
+        if kind == "pinned":
+            for a in (src, cbuf, back):
+                mic.host_free(a.reshape(-1).view(np.uint8) if a.dtype != np.uint8 else a)
+        return r
+
+    out = {"what": f"mic_hip_pics_compress_batch + mic_hip_pics_decompress_batch, {B} frames ({B * S} strips) per call, host buffers in and out",
+           "pcie_pinned_GBps": {k: round(v, 2) for k, v in rates.items()},
+           "pageable": run("pageable"), "pinned": run("pinned")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +368,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip configs 3-5 and the batch sweep")
     ap.add_argument("--legs-only", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) figure")
     args = ap.parse_args()
 
     import torch
@@ -412,6 +487,10 @@ def main():
             "container_assembly": assembly,
         }
     sess.close()
+
+    if world == 1 and not args.no_e2e and not args.legs_only:
+        out["end_to_end"] = leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev)
+        torch.cuda.empty_cache()
 
     if world == 1 and not args.no_legs:
         # B in {1, 64, 288, 512}: kernel time of one encode+decode per batch size (report B = 1 honestly)

@@ -128,9 +128,19 @@ typedef struct mic_hip_dec_job {
     int32_t   status;          /* out */
 } mic_hip_dec_job;
 
-/* Return value: MIC_OK when the batch ran (inspect per-job status), or a global error. */
+/* Return value: MIC_OK when the batch ran (inspect per-job status), or a global error.
+ * Host buffers are ordinary (pageable) memory or pinned memory (below); large batches run as a pipeline of sub-batches --
+ * upload, kernels and download of neighbouring sub-batches overlap -- and concurrent callers run on different sessions of a
+ * small pool (MIC_HIP_POOL sessions, default 3), as the reference's C codec runs concurrent goroutines (ojph/mic_parallel.h:47-48). */
 int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs);
 int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs);
+
+/* Pinned host memory (hipHostMalloc) for a caller's frame and stream buffers: every entry point that takes host pointers
+ * recognises such memory -- and memory the caller registered itself -- and DMAs it in place; ordinary memory (a Go slice) is staged
+ * through pinned slots by the library's transfer threads (MIC_HIP_IO_THREADS, default half the host's cores, at most 8).
+ * A cgo caller wraps the pointer with unsafe.Slice. */
+void *mic_hip_host_alloc(size_t bytes);
+void  mic_hip_host_free(void *p);
 
 /* ---- PICS container --------------------------------------------------------------------- */
 /* Replaces CompressParallelStrips{,4State,8State} (parallelstrips.go:55,128,199).
@@ -147,6 +157,29 @@ int mic_hip_pics_info(const uint8_t *compressed, size_t compressed_len,
  * width/height must equal the header's. */
 int mic_hip_pics_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *pixels_out, int width, int height);
+/* Many images, one call: the strips of ALL jobs are one unit batch (the reference reaches the same parallelism by calling
+ * CompressParallelStrips from many goroutines, each fanning out its strips: parallelstrips.go:77-93; a single image is eight
+ * serial entropy chains and leaves the device idle).  Every job's file equals mic_hip_pics_compress's, byte for byte. */
+typedef struct mic_hip_pics_enc_job {
+    const uint16_t *pixels;   /* in : width*height u16 (host memory) */
+    int32_t   width, height;  /* in  */
+    uint16_t  max_value;      /* in  */
+    uint16_t  nstates;        /* in : MIC_STATES_2/4/8 */
+    int32_t   num_strips;     /* in : > 0 */
+    uint8_t  *out;            /* in : caller buffer, out_cap >= MIC_HIP_PICS_BOUND(...) is always sufficient */
+    size_t    out_cap;        /* in  */
+    size_t    out_len;        /* out */
+    int32_t   status;         /* out */
+} mic_hip_pics_enc_job;
+typedef struct mic_hip_pics_dec_job {
+    const uint8_t *compressed; /* in : a PICS file (host memory) */
+    size_t    compressed_len;  /* in  */
+    uint16_t *pixels_out;      /* in : width*height u16 (host memory) */
+    int32_t   width, height;   /* in : must equal the header's */
+    int32_t   status;          /* out */
+} mic_hip_pics_dec_job;
+int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs);
+int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs);
 
 /* Replaces CompressSingleFrameGrad / DecompressSingleFrameGrad (multiframecompress.go:111-142): the unit codec with the
  * gradient-adaptive predictor (deltagradrlecompressu16.go) and the two-state -> one-state FSE chain. */

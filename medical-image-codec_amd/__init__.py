@@ -75,6 +75,17 @@ class DecJob(C.Structure):
                 ("status", C.c_int32)]
 
 
+class PicsEncJob(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_value", C.c_uint16), ("nstates", C.c_uint16), ("num_strips", C.c_int32),
+                ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_len", C.c_size_t), ("status", C.c_int32)]
+
+
+class PicsDecJob(C.Structure):
+    _fields_ = [("compressed", C.c_void_p), ("compressed_len", C.c_size_t),
+                ("pixels_out", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("status", C.c_int32)]
+
+
 class Unit(C.Structure):
     _fields_ = [("px_offset", C.c_uint64), ("width", C.c_int32), ("height", C.c_int32),
                 ("max_value", C.c_uint16), ("nstates", C.c_uint16)]
@@ -85,8 +96,8 @@ ABI_SYMBOLS = [
     "mic_hip_set_device", "mic_hip_device_name", "mic_hip_version",
     "mic_hip_compress_frame", "mic_hip_decompress_frame",
     "mic_hip_fse_compress_u16", "mic_hip_fse_decompress_u16_auto", "mic_hip_fse_compress_u16_ex", "mic_hip_fse_decompress_u16_ex",
-    "mic_hip_compress_batch", "mic_hip_decompress_batch",
-    "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress",
+    "mic_hip_compress_batch", "mic_hip_decompress_batch", "mic_hip_host_alloc", "mic_hip_host_free",
+    "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress", "mic_hip_pics_compress_batch", "mic_hip_pics_decompress_batch",
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_compress_batch", "mic_hip_wavelet_v2_decompress_batch", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
@@ -146,6 +157,12 @@ def lib() -> C.CDLL:
     L.mic_hip_decompress_batch.argtypes = [C.POINTER(DecJob), C.c_int]
     L.mic_hip_pics_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_int,
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_pics_compress_batch.argtypes = [C.POINTER(PicsEncJob), C.c_int]
+    L.mic_hip_pics_decompress_batch.argtypes = [C.POINTER(PicsDecJob), C.c_int]
+    L.mic_hip_host_alloc.argtypes = [C.c_size_t]
+    L.mic_hip_host_alloc.restype = C.c_void_p
+    L.mic_hip_host_free.argtypes = [C.c_void_p]
+    L.mic_hip_host_free.restype = None
     L.mic_hip_pics_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.mic_hip_pics_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
     L.mic_hip_mic2_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint16,
@@ -315,6 +332,68 @@ def compress_parallel_strips(pixels, width: int, height: int, max_value: int, nu
     if rc:
         _raise(rc, "compress_parallel_strips")
     return out[: n.value].tobytes()
+
+
+def pics_bound(width: int, height: int, num_strips: int) -> int:
+    """MIC_HIP_PICS_BOUND"""
+    ns = max(num_strips, 1)
+    return 20 + 8 * ns + 4 * width * height + 135168 * ns
+
+
+def compress_parallel_strips_batch(images: Sequence[np.ndarray], max_value: int, num_strips: int, nstates: int = 2,
+                                   outs: Optional[Sequence[np.ndarray]] = None) -> List[Tuple[int, "np.ndarray"]]:
+    """Many images, one call (mic_hip_pics_compress_batch): [(status, file bytes as a uint8 view of its out buffer)].
+    images: (height, width) uint16 arrays (ordinary or pinned memory); outs: caller buffers of >= pics_bound bytes, or None."""
+    n = len(images)
+    arrs = [_u16(a) for a in images]
+    if outs is None:
+        outs = [np.empty(pics_bound(a.shape[1], a.shape[0], num_strips), dtype=np.uint8) for a in arrs]
+    jobs = (PicsEncJob * n)()
+    for i, a in enumerate(arrs):
+        jobs[i].pixels = a.ctypes.data; jobs[i].width = a.shape[1]; jobs[i].height = a.shape[0]
+        jobs[i].max_value = max_value; jobs[i].nstates = nstates; jobs[i].num_strips = num_strips
+        jobs[i].out = outs[i].ctypes.data; jobs[i].out_cap = outs[i].size
+    rc = lib().mic_hip_pics_compress_batch(jobs, n)
+    if rc:
+        _raise(rc, "compress_parallel_strips_batch")
+    return [(jobs[i].status, outs[i][: jobs[i].out_len]) for i in range(n)]
+
+
+def decompress_parallel_strips_batch(files: Sequence, dims: Sequence[Tuple[int, int]],
+                                     outs: Optional[Sequence[np.ndarray]] = None) -> List[Tuple[int, "np.ndarray"]]:
+    """Many PICS files, one call (mic_hip_pics_decompress_batch): [(status, (height, width) uint16 pixels)]."""
+    n = len(files)
+    cs = [_bytes_arr(f) for f in files]
+    if outs is None:
+        outs = [np.empty(w * h, dtype=np.uint16) for (w, h) in dims]
+    jobs = (PicsDecJob * n)()
+    for i in range(n):
+        jobs[i].compressed = cs[i].ctypes.data; jobs[i].compressed_len = cs[i].size
+        jobs[i].pixels_out = outs[i].ctypes.data; jobs[i].width = dims[i][0]; jobs[i].height = dims[i][1]
+    rc = lib().mic_hip_pics_decompress_batch(jobs, n)
+    if rc:
+        _raise(rc, "decompress_parallel_strips_batch")
+    return [(jobs[i].status, outs[i].reshape(dims[i][1], dims[i][0])) for i in range(n)]
+
+
+def host_alloc(nbytes: int, dtype=np.uint8) -> np.ndarray:
+    """A pinned host buffer (mic_hip_host_alloc) as a numpy array; free it with host_free(arr)."""
+    p = lib().mic_hip_host_alloc(nbytes)
+    if not p:
+        raise MicError(MIC_ERR_NOMEM, "host_alloc")
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    a = np.frombuffer(buf, dtype=np.uint8).view(dtype)
+    _PINNED[a.ctypes.data] = p
+    return a
+
+
+def host_free(a: np.ndarray) -> None:
+    p = _PINNED.pop(a.ctypes.data, None)
+    if p:
+        lib().mic_hip_host_free(p)
+
+
+_PINNED = {}
 
 
 def pics_info(compressed) -> Tuple[int, int, int, int]:

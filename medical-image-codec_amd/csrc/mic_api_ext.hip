@@ -204,7 +204,7 @@ struct TileBlob { const uint8_t *p; size_t len; };
 int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::vector<int4> &place,
                  uint8_t *rgb_out, int dst_w, int dst_h) {
     if (!m.supported()) return MIC_ERR_UNSUPPORTED;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     const size_t npx = (size_t)m.tw * m.th;
     const size_t ntile = tiles.size();
     const size_t P = (size_t)m.planes(), bpp = m.bpp();
@@ -390,10 +390,10 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
     if (tile_w == 0) tile_w = 256;                                                          // WSIOptions.defaults, wsiformat.go:86-96
     if (tile_h == 0) tile_h = 256;
     if ((size_t)tile_w * tile_h > ((size_t)1 << 26) || levels > 32) return MIC_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     if ((rc = s->ensure(1, (size_t)tile_w * tile_h))) return rc;
     const std::vector<Level> lv = plan_levels(width, height, tile_w, tile_h, levels);
     const int nlev = (int)lv.size();
@@ -454,10 +454,10 @@ int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out
     if (!rgb || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
     Mic3 fmt; fmt.channels = 3; fmt.bps = 8; fmt.flags = 0x03;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     if ((rc = s->ensure(1, (size_t)width * height))) return rc;
     DevBuf img;
     if ((rc = img.reserve((size_t)width * height * 3 + 64))) return rc;
@@ -478,8 +478,8 @@ int mic_hip_rgb_decompress(const uint8_t *c, size_t len, int width, int height, 
     if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
     if ((size_t)width * height * 3 > out_cap) return MIC_ERR_CAPACITY;
     Mic3 m; m.w = width; m.h = height; m.tw = width; m.th = height; m.channels = 3; m.bps = 8; m.flags = 0x03; m.nlev = 1; m.total = 1; m.data_off = 0;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
     return decode_blobs(m, std::vector<TileBlob>(1, TileBlob{ c, len }), std::vector<int4>(1, make_int4(0, 0, width, height)), rgb_out, width, height);
 }
@@ -587,8 +587,8 @@ int mic_hip_wsi_decompress_tile(const uint8_t *c, size_t len, int level, int til
     if (!m.supported()) return MIC_ERR_UNSUPPORTED;
     if ((size_t)aw * ah * m.bpp() > out_cap) return MIC_ERR_CAPACITY;
     if (out_w) *out_w = aw; if (out_h) *out_h = ah;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ensure_device())) return rc;
+    DefaultLease lease;
+    if ((rc = lease.acquire())) return rc;
     std::vector<size_t> tiles(1, (size_t)L.first + (size_t)tile_y * L.tx + tile_x);
     std::vector<int4> place(1, make_int4(0, 0, aw, ah));
     return decode_tiles(c, len, m, tiles, place, rgb_out, aw, ah);
@@ -611,8 +611,8 @@ int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_
         tiles.push_back((size_t)L.first + (size_t)ty * L.tx + tx);
         place.push_back(make_int4(tx * m.tw, ty * m.th, aw, ah));
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ensure_device())) return rc;
+    DefaultLease lease;
+    if ((rc = lease.acquire())) return rc;
     return decode_tiles(c, len, m, tiles, place, rgb_out, L.w, L.h);
 }
 
@@ -645,8 +645,8 @@ int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x
     }
     std::vector<uint8_t> box((size_t)bw * bh * bpp);
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if ((rc = ensure_device())) return rc;
+        DefaultLease lease;
+        if ((rc = lease.acquire())) return rc;
         if ((rc = decode_tiles(c, len, m, tiles, place, box.data(), bw, bh))) return rc;
     }
     for (int r = 0; r < h; r++)

@@ -12,114 +12,6 @@
 #include "mic_launch.h"
 
 // ------------------------------------------------------------------------------------------
-// RLE tokeniser, exact statement of RleCompressU16.{Encode,Flush} without the side buffer:
-// pending literals are written behind a reserved header slot and the slot is patched (or the
-// reservation rolled back) when the reference would have emitted the chunk.
-struct RleTok {
-    uint16_t *out; uint32_t cap, n;   // token stream and fill
-    uint32_t hdr_pos;                 // reserved header slot of the open literal chunk
-    uint32_t bc;                      // len(r.b)
-    uint16_t mid, p1, p2, v;          // midCount, last two symbols, value of the same-run
-    bool same, overflow;
-
-    __device__ void put(uint32_t pos, uint16_t x) { if (pos < cap) out[pos] = x; else overflow = true; }
-    __device__ void append(uint16_t x) {
-        if (!same) {
-            if (bc == 0) { hdr_pos = n; n++; }
-            put(hdr_pos + 1 + bc, x);
-            n = hdr_pos + 1 + bc + 1;
-        }
-        bc++;
-        p2 = p1; p1 = x;
-    }
-    __device__ void close_literals(uint32_t keep) {  // emit all but the last `keep` pending literals
-        uint32_t cnt = bc - keep;
-        put(hdr_pos, (uint16_t)(mid + (uint16_t)cnt));
-        n = hdr_pos + 1 + cnt;
-    }
-    __device__ void encode(uint16_t x) {              // rlecompressu16.go:24-70
-        if (bc < 2) { append(x); return; }
-        if (p2 == p1 && p1 == x) {
-            if (!same) {
-                if (bc > 2) close_literals(2);
-                else n = hdr_pos;                     // the two pending symbols join the run
-                bc = 2; v = x;                        // r.b = r.b[bc-2:]
-            }
-            same = true;
-        } else {
-            if (same && bc > 2) {
-                put(n, (uint16_t)bc); put(n + 1, v); n += 2;
-                bc = 0;
-            }
-            same = false;
-        }
-        if ((int)bc >= (int)(uint16_t)(mid - 1)) {    // count overflow, :57-67
-            if (same) {
-                put(n, (uint16_t)(bc - 2)); put(n + 1, v); n += 2;
-            } else {
-                uint16_t a = (hdr_pos + 1 + bc - 2 < cap) ? out[hdr_pos + 1 + bc - 2] : 0;
-                uint16_t b = (hdr_pos + 1 + bc - 1 < cap) ? out[hdr_pos + 1 + bc - 1] : 0;
-                close_literals(2);
-                hdr_pos = n; n++;
-                put(hdr_pos + 1, a); put(hdr_pos + 2, b);
-                n = hdr_pos + 3;
-            }
-            bc = 2;
-        }
-        append(x);
-    }
-    __device__ void flush() {                          // rlecompressu16.go:72-83
-        if (bc > 0) {
-            if (same) { put(n, (uint16_t)bc); put(n + 1, v); n += 2; }
-            else close_literals(0);
-        }
-    }
-};
-
-// v0: one lane walks the unit.  grid = units, block = 64.
-__global__ void __launch_bounds__(64) k_enc_tokens_serial(MicUnit *units) {
-    MicUnit &u = units[blockIdx.x];
-    if (threadIdx.x != 0 || u.mode != 0) return;
-    u.status = MICD_OK; u.ntok = 0; u.blob_len = 0; u.nstates_used = 0;
-    int depth = mic_len16(u.max_value);
-    if (u.w <= 0 || u.h <= 0) { u.status = MICD_ERR_ARGS; return; }
-    // max_value < 8 (midCount < 7): the reference's RLE chunking degenerates (empty literal
-    // chunks / slice panics in rlecompressu16.go:57-67), so there is no behaviour to match.
-    if (depth < 4) { u.status = MICD_ERR_UNSUPPORTED; return; }
-    const uint16_t thr = (uint16_t)((1u << (depth - 1)) - 1);
-    const uint16_t delim = (uint16_t)((1u << depth) - 1);
-    RleTok r;
-    r.out = u.tok; r.cap = u.tok_cap; r.n = 0; r.hdr_pos = 0; r.bc = 0;
-    r.mid = (uint16_t)((1u << (mic_len16(delim) - 1)) - 1);
-    r.p1 = r.p2 = r.v = 0; r.same = false; r.overflow = false;
-    r.put(0, delim); r.n = 1;                          // rlecompressu16.go:21
-    r.encode(u.max_value);                             // deltarlecompressu16.go:29
-    const uint16_t *in = u.px_in;
-    const int w = u.w, h = u.h;
-    for (int y = 0; y < h; y++) {
-        for (int x = 0; x < w; x++) {
-            size_t idx = (size_t)y * w + x;
-            int32_t prev = 0; int div = 0;
-            if (u.pred) prev = mic_grad_predict_at(in, w, x, y);
-            else {
-                if (x > 0) { prev = in[idx - 1]; div++; }
-                if (y > 0) { prev += in[idx - w]; div++; }
-                if (div == 2) prev >>= 1;
-            }
-            uint16_t val = in[idx];
-            int32_t diff = (int32_t)val - prev;
-            int32_t m = diff >> 31;
-            int32_t ad = (diff ^ m) - m;
-            if ((uint16_t)ad >= thr) { r.encode(delim); r.encode(val); }
-            else r.encode((uint16_t)((int32_t)thr + diff));
-        }
-    }
-    r.flush();
-    if (r.overflow) { u.status = MICD_ERR_CAPACITY; return; }
-    u.ntok = r.n;
-}
-
-// ------------------------------------------------------------------------------------------
 // Parallel Delta(avg) + RLE tokeniser: one work-group of 1024 threads per unit.
 //
 // The reference tokeniser (rlecompressu16.go:24-83) is a serial state machine, but its output
@@ -683,74 +575,7 @@ __global__ void __launch_bounds__(256) k_enc_symbols(MicUnit *units) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Histogram of the token stream.  grid = (blocks_per_unit, units), block = 256.
-// hist must be zero on entry (the launcher memsets the workspace slab).
-__global__ void __launch_bounds__(256) k_enc_hist(MicUnit *units) {
-    MicUnit &u = units[blockIdx.y];
-    if (u.status != MICD_OK) return;
-    const uint32_t n = u.ntok;
-    const uint16_t *tok = u.tok;
-    uint32_t *hist = u.hist;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&hist[tok[i]], 1u);
-}
 
-// ------------------------------------------------------------------------------------------
-// Gates + tables.  grid = units, block = 256.  The table maths is the reference's serial code
-// (mic_fse_tables.h); what this kernel adds is locality: for the common case (alphabet <= 8192
-// symbols, tableLog <= 13) the histogram, norm[], cumul[] and tableSymbol[] working arrays live
-// in LDS, so the single lane that runs the data-dependent loops pays ~70-cycle LDS latencies
-// instead of HBM/L2 round trips; stateTable / symbolTT go straight to HBM as stores.
-#define ET_SMALL_SYMS 8192
-#define ET_SMALL_TL 13
-__global__ void __launch_bounds__(256) k_enc_tables(MicUnit *units) {
-    MicUnit &u = units[blockIdx.x];
-    if (u.status != MICD_OK) return;
-    __shared__ uint32_t s_max[256], s_len[256];
-    __shared__ uint32_t s_hist[ET_SMALL_SYMS];
-    __shared__ int32_t s_norm[ET_SMALL_SYMS];
-    __shared__ int32_t s_cumul[ET_SMALL_SYMS + 8];
-    __shared__ uint16_t s_tabsym[1 << ET_SMALL_TL];
-    uint32_t m = 0, sl = 0;
-    for (uint32_t i = threadIdx.x; i <= MIC_MAXSYM; i += blockDim.x) {
-        uint32_t c = u.hist[i];
-        if (i < ET_SMALL_SYMS) s_hist[i] = c;
-        if (c) { if (c > m) m = c; if (i + 1 > sl) sl = i + 1; }
-    }
-    s_max[threadIdx.x] = m; s_len[threadIdx.x] = sl;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            if (s_max[threadIdx.x + s] > s_max[threadIdx.x]) s_max[threadIdx.x] = s_max[threadIdx.x + s];
-            if (s_len[threadIdx.x + s] > s_len[threadIdx.x]) s_len[threadIdx.x] = s_len[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const uint32_t n = u.ntok;
-    u.max_count = s_max[0]; u.symbol_len = s_len[0];
-    // Gate order of FSECompressU16* (fse2state.go:23-42); the length gate depends on the
-    // flavour and is applied per attempt in k_enc_tans.
-    if (n <= 1 || (u.no_fallback && n <= (u.nstates == 108 ? 8u : (uint32_t)u.nstates) - 1)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
-    if (u.max_count == n) { u.status = MICD_ERR_USE_RLE; return; }
-    if (u.max_count == 1 || u.max_count < (n >> 15)) { u.status = MICD_ERR_INCOMPRESSIBLE; return; }
-    u.table_log = mic_optimal_table_log(n, u.symbol_len, u.req_tl);
-    const bool small = u.symbol_len <= ET_SMALL_SYMS && u.table_log <= ET_SMALL_TL;
-    MicUnit v = u;                                  // working copy whose scratch arrays may point into LDS
-    const uint32_t *hist = u.hist;
-    if (small) { hist = s_hist; v.norm = s_norm; v.cumul = s_cumul; v.tab_sym = s_tabsym; }
-    int rc = mic_normalize_count(hist, v.norm, v.symbol_len, n, v.table_log);
-    if (rc) { u.status = rc; return; }
-    if (u.blob_cap < 6 + 8) { u.status = MICD_ERR_CAPACITY; return; }
-    rc = mic_write_ncount(v.norm, v.symbol_len, v.table_log, u.blob + 6, u.blob_cap - 6, &v.hdr_len);
-    if (rc) { u.status = rc; return; }
-    u.hdr_len = v.hdr_len;
-    for (int k = 0; k < 8; k++) u.blob[6 + u.hdr_len + k] = 0;   // k_enc_tans_wg ORs into the first stream word
-    rc = mic_build_ctable(v);
-    if (rc) { u.status = rc; return; }
-    u.zero_bits = v.zero_bits;
-}
 
 // ------------------------------------------------------------------------------------------
 // LSB-first bit writer (bitwriter.go:50-53, :162-168).  The reference's flush32 cadence never
@@ -1302,53 +1127,34 @@ __global__ void __launch_bounds__(256) k_enc_hist_clean(MicUnit *units) {
 // launchers
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
     const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
-    variant &= ~MIC_VARIANT_GRAD;
     if (t) t->mark("k_enc_symbols");
     hipLaunchKernelGGL(k_enc_symbols, dim3(64, n), dim3(256), 0, stream, d_units);
-    if (variant == 100) {
-        if (t) t->mark("k_enc_tokens_serial");
-        hipLaunchKernelGGL(k_enc_tokens_serial, dim3(n), dim3(64), 0, stream, d_units);
-    } else {
-        if (t) t->mark("k_enc_tokens_wg");
-        hipLaunchKernelGGL(k_enc_tokens_wg<0>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
-        hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
-        if (any_grad) hipLaunchKernelGGL((k_enc_tokens_wg<0, 1>), dim3(n), dim3(TK_THREADS), 0, stream, d_units);
-    }
-    if (variant == 100) {
-        if (t) t->mark("k_enc_hist");
-        hipLaunchKernelGGL(k_enc_hist, dim3(64, n), dim3(256), 0, stream, d_units);
-    }
-    if (variant == 100) {
-        if (t) t->mark("k_enc_tables");
-        hipLaunchKernelGGL(k_enc_tables, dim3(n), dim3(256), 0, stream, d_units);
-    } else {
-        if (t) t->mark("k_enc_tables_wg");
-        mic_launch_enc_tables(d_units, n, stream);
-    }
-    if (variant != 100) {
-        static MicPerDeviceOnce once;
-        once.run([] {
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        });
-        if (t) t->mark("k_enc_tans_wg<13>");
-        hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
-        if (t) t->mark("k_enc_tans_wg<13, one wave>");
-        hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8, stream, d_units);
-        hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8, stream, d_units);
-        if (t) t->mark("k_enc_tans_wg<other classes>");
-        hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
-        hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
-        hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
-    }
+    if (t) t->mark("k_enc_tokens_wg");
+    hipLaunchKernelGGL(k_enc_tokens_wg<0>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+    hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+    if (any_grad) hipLaunchKernelGGL((k_enc_tokens_wg<0, 1>), dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+    if (t) t->mark("k_enc_tables_wg");
+    mic_launch_enc_tables(d_units, n, stream);
+    static MicPerDeviceOnce once;
+    once.run([] {
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (t) t->mark("k_enc_tans_wg<13>");
+    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
+    if (t) t->mark("k_enc_tans_wg<13, one wave>");
+    hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8, stream, d_units);
+    if (t) t->mark("k_enc_tans_wg<other classes>");
+    hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
-    if (variant != 100) {
-        if (t) t->mark("k_enc_hist_clean");
-        hipLaunchKernelGGL(k_enc_hist_clean, dim3(n), dim3(256), 0, stream, d_units);
-    }
+    if (t) t->mark("k_enc_hist_clean");
+    hipLaunchKernelGGL(k_enc_hist_clean, dim3(n), dim3(256), 0, stream, d_units);
     if (t) t->mark("end");
 }
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t) {

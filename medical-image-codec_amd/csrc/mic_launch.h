@@ -46,9 +46,7 @@ struct MicTimer {
     void destroy() { for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); used = 0; names.clear(); }
 };
 
-// variant: 0 = the shipped kernels, 1 = the two-streams-per-wave tANS decoder of round 1 (k_dec_tans_duo) instead of the
-// lane-per-state one, 100 = the serial reference kernels; | MIC_VARIANT_GRAD when some unit has pred = 1 (their
-// tokeniser / predictor instantiations are only launched then)
+// variant: launch flags -- MIC_VARIANT_GRAD when some unit has pred = 1 (their tokeniser / predictor instantiations are only launched then)
 #define MIC_VARIANT_GRAD 0x1000
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 // d_cls: per-session scratch of MIC_CLS_INTS(n) ints for the per-class unit lists of the lane-per-state tANS decoder (mic_decode_ls.hip)

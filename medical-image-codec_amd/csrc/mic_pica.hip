@@ -62,10 +62,10 @@ int mic_hip_compress_frame_grad(const uint16_t *pixels, int width, int height, u
     if (!pixels || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     const size_t npx = (size_t)width * (size_t)height;
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     if ((rc = s->ensure(1, npx))) return rc;
     if ((rc = s->io_px.reserve(npx * 2 + 64))) return rc;
     HIP_TRY(hipMemcpyAsync(s->io_px.p, pixels, npx * 2, hipMemcpyHostToDevice, s->stream));
@@ -87,10 +87,10 @@ int mic_hip_decompress_frame_grad(const uint8_t *c, size_t len, uint16_t *pixels
     if (len == 0) return MIC_ERR_CORRUPT;
     const size_t npx = (size_t)width * (size_t)height;
     if (npx > ((size_t)1 << 28) || len > 0xFFFFFFF0ull) return MIC_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     if ((rc = s->ensure(1, npx))) return rc;
     if ((rc = s->io_px.reserve(npx * 2 + 64))) return rc;
     if ((rc = s->io_comp.reserve(len + 64))) return rc;
@@ -111,10 +111,10 @@ int mic_hip_pica_compress(const uint16_t *pixels, int width, int height, uint16_
     if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
     if ((size_t)width * (size_t)height > ((size_t)1 << 31)) return MIC_ERR_UNSUPPORTED;
     if (num_strips > height) num_strips = height;                                          // :61-66
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     if ((rc = s->ensure(1, 1))) return rc;                                                  // (the stream)
     const size_t npx = (size_t)width * (size_t)height;
     if ((rc = s->io_px.reserve(npx * 2 + 64))) return rc;
@@ -226,9 +226,9 @@ int mic_hip_pica_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, 
         if (t.end > len || t.start > t.end) return MIC_ERR_CORRUPT;                         // :186-190
         if (t.y0 < 0 || t.y1 <= t.y0 || t.y1 > h) return MIC_ERR_CORRUPT;                   // Go: make / slice panics
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ensure_device())) return rc;
-    mic_hip_session *s = &g_default;
+    DefaultLease lease;
+    if ((rc = lease.acquire())) return rc;
+    mic_hip_session *s = cur_default();
     const size_t npx = (size_t)w * (size_t)h;
     if ((rc = s->ensure(1, 1))) return rc;
     if ((rc = s->io_px.reserve(npx * 2 + 64))) return rc;

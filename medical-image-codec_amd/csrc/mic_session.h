@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -26,10 +27,8 @@
 
 namespace micapi {
 
-extern std::mutex g_mu;     // serialises the default session (entry points are re-entrant)
+extern std::mutex g_mu;     // guards the device choice and the pool of default sessions (mic_api.hip)
 extern int g_device;
-extern bool g_device_ok;
-extern std::string g_device_name;
 int ensure_device();
 int check_device(int device);      // MIC_OK when `device` exists and is gfx950 (cached per device)
 
@@ -69,26 +68,25 @@ struct mic_hip_session {
     int activate() { return hipSetDevice(device) == hipSuccess ? MIC_OK : MIC_ERR_DEVICE; }
     DevBuf units, cls, tok, hist, norm, tt_nb, tt_find, state_tab, tab_sym, cumul, blob, packed, offsets, seg, sym, flags;
     DevBuf io_px, io_comp;                 // staging for the host-pointer entry points
+    DevBuf io_px2, io_comp2, packed2;      // their second halves: sub-batch k + 1 comes up while k is coded and k - 1 goes down (mic_host_io.hip)
     DevBuf wv_a, wv_b;                     // WaveletV2 coefficient planes (int32, two per frame of the batch)
     mic_hip_wsi_store *wsi = nullptr;      // mic_hip_session_wsi_*: coded planes of a slide, on the device
     DevBuf wsi_planes, wsi_stats; std::vector<DevBuf> wsi_pyr;
     std::vector<MicUnit> h_units;
     std::vector<uint64_t> h_off;
     int n_last = 0;
-    int variant = 0;                        // kernel generation selector (0 = default)
+    int variant = 0;                        // launch flags (MIC_VARIANT_GRAD is OR-ed in per call)
     // The per-unit 65536-bin histograms are ZERO between calls: the encode chain leaves them so (k_enc_hist_clean re-zeroes what a
     // unit's tokeniser counted), and nothing else writes them.  hist_zero_units = leading unit slabs known to be zero (0 after a
-    // reallocation, after the serial kernel generation, after a failed launch).  The invariant is tied to the ALLOCATION (DevBuf::gen),
+    // reallocation, after a failed launch).  The invariant is tied to the ALLOCATION (DevBuf::gen),
     // not to the address: hipFree + a larger hipMalloc may hand the same address back with undefined contents.
     uint64_t hist_zero_gen = ~0ull; size_t hist_zero_units = 0;
     int prepare_hist(int n) {
         if (hist.gen != hist_zero_gen) { hist_zero_gen = hist.gen; hist_zero_units = 0; }
-        if (variant == 100) hist_zero_units = 0;
         if ((size_t)n > hist_zero_units) {
             HIP_TRY(hipMemsetAsync((char *)hist.p + kSym * 4 * hist_zero_units, 0, kSym * 4 * ((size_t)n - hist_zero_units), stream));
             hist_zero_units = (size_t)n;
         }
-        if (variant == 100) hist_zero_units = 0;                          // (that generation does not clean up behind itself)
         return MIC_OK;
     }
     void hist_unknown() { hist_zero_units = 0; }
@@ -145,8 +143,14 @@ struct mic_hip_session {
         u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px) + 64, 0xFFFFFFF0u);
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
+    size_t reserved_bytes() const {
+        const DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
+        size_t t = 0;
+        for (const DevBuf *b : all) t += b->cap;
+        return t;
+    }
     void release() {
-        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
+        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
         for (DevBuf *b : all) b->release();
         for (DevBuf &b : wsi_pyr) b.release();
         wsi_pyr.clear();
@@ -159,7 +163,16 @@ struct mic_hip_session {
 
 
 namespace micapi {
-extern mic_hip_session g_default;   // guarded by g_mu
+// A session of the default pool, held by the calling thread for the duration of a host-pointer entry point (mic_api.hip).
+struct DefaultLease {
+    mic_hip_session *s = nullptr; bool held = false;
+    int acquire();                  // MIC_OK, or why there is no device; blocks while every pooled session is out
+    ~DefaultLease();
+    DefaultLease() = default;
+    DefaultLease(const DefaultLease &) = delete;
+    DefaultLease &operator=(const DefaultLease &) = delete;
+};
+mic_hip_session *cur_default();     // the session the calling thread holds
 int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n);
 int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates);
 int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
@@ -173,18 +186,6 @@ size_t unit_ws_bytes(size_t px);
 int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
                            uint8_t *out, size_t out_cap, size_t *out_len);
 int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_total, int n, uint16_t *frames_out);
-// Per-call workspace ceiling: the container entry points cut their unit lists into sub-batches that stay under it.
-// MIC_HIP_WS_BUDGET_MB (read once) lowers it so that tests can walk the sub-batch loops with small inputs.
-inline size_t workspace_budget() {
-    static const size_t v = [] {
-        const char *e = getenv("MIC_HIP_WS_BUDGET_MB");
-        const long mb = e ? atol(e) : 0;
-        if (mb > 0) return (size_t)mb << 20;
-        size_t fr = 0, tot = 0;                                            // a quarter of the device (72 GiB of an MI355X's 288), at least 8 GiB
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)96 << 30;
-        return std::max<size_t>(tot / 4, (size_t)8 << 30);
-    }();
-    return v;
-}
+size_t workspace_budget();        // per-call workspace ceiling (mic_api.hip)
 #define kWorkspaceBudget (micapi::workspace_budget())
 }  // namespace micapi

@@ -76,10 +76,10 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
     const size_t header = 20 + (size_t)nframes * 8;
     if (out_cap < header) return MIC_ERR_CAPACITY;
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (unit_ws_bytes(npx) + 2 * npx), 65535));
     std::vector<uint32_t> lens((size_t)nframes);
     uint64_t total = 0;
@@ -139,10 +139,10 @@ int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_t
     const size_t npx = (size_t)w * (size_t)h;
     if (npx > ((size_t)1 << 28) || len > 0xFFFFFFF0ull) return MIC_ERR_UNSUPPORTED;
     const size_t data_off = 20 + (size_t)n_total * 8;                      // decodes frames 0 .. n-1 of n_total
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     const size_t per = std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (unit_ws_bytes(npx) + 2 * npx), 65535));
     for (size_t f0 = 0; f0 < (size_t)n; f0 += per) {
         const int nb = (int)std::min(per, (size_t)n - f0);

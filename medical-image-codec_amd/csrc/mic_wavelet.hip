@@ -852,10 +852,10 @@ int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int r
     if (levels > 8) levels = 8;
     int applied = 0;
     { int r = rows, c = cols; for (; applied < levels; applied++) { if (r < 2 || c < 2) break; r = (r + 1) / 2; c = (c + 1) / 2; } }   // :321-330
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = ensure_device();
+    DefaultLease lease;
+    int rc = lease.acquire();
     if (rc) return rc;
-    mic_hip_session *s = &g_default;
+    mic_hip_session *s = cur_default();
     const size_t per = wv_frames_per_batch(n);
     for (size_t f0 = 0; f0 < (size_t)nframes; f0 += per) {
         const int nf = (int)std::min(per, (size_t)nframes - f0);
@@ -912,9 +912,9 @@ int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_
     const size_t n = (size_t)rows * (size_t)cols;
     if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
     if (n * (size_t)nframes > out_cap_px) return MIC_ERR_CAPACITY;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if ((rc = ensure_device())) return rc;
-    mic_hip_session *s = &g_default;
+    DefaultLease lease;
+    if ((rc = lease.acquire())) return rc;
+    mic_hip_session *s = cur_default();
     const size_t per = wv_frames_per_batch(n);
     for (size_t f0 = 0; f0 < (size_t)nframes; f0 += per) {
         const int nf = (int)std::min(per, (size_t)nframes - f0);

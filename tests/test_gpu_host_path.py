@@ -1,0 +1,161 @@
+"""GPU tests of the host-pointer path (mic_host_io.hip): the batch entry points over ordinary and pinned host memory, the
+sub-batch pipeline, and concurrent callers (the header promises what ojph/mic_parallel.h:47-48 promises: any thread, any time).
+Everything is compared with the oracle, bit for bit."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(synth, n, w=322, h=256, depth=12):
+    return [synth.xr_like(cols=w, rows=h, depth=depth, seed=100 + i) for i in range(n)]
+
+
+def test_pics_batch_equals_single_calls_and_the_oracle(mic, mico, synth, gpu_ready):
+    imgs = _images(synth, 5) + [synth.xr_like(cols=129, rows=77, depth=10, seed=7)]
+    maxv = 4095
+    res = mic.compress_parallel_strips_batch(imgs, maxv, 8, 2)
+    files = []
+    for img, (st, blob) in zip(imgs, res):
+        assert st == 0
+        rc, want = mico.pics_compress(img, maxv, 8, 2)
+        assert rc == 0 and blob.tobytes() == want
+        assert blob.tobytes() == mic.compress_parallel_strips(img, img.shape[1], img.shape[0], maxv, 8)
+        files.append(blob.tobytes())
+    out = mic.decompress_parallel_strips_batch(files, [(i.shape[1], i.shape[0]) for i in imgs])
+    for img, (st, px) in zip(imgs, out):
+        assert st == 0 and np.array_equal(px, img)
+
+
+def test_pics_batch_reports_errors_per_job(mic, mico, synth, gpu_ready):
+    imgs = _images(synth, 3)
+    rc, good = mico.pics_compress(imgs[0], 4095, 4, 2)
+    bad_magic = b"XXXX" + good[4:]
+    truncated = good[: len(good) // 2]
+    out = mic.decompress_parallel_strips_batch([good, bad_magic, truncated, good], [(322, 256)] * 4)
+    assert out[0][0] == 0 and np.array_equal(out[0][1], imgs[0])
+    assert out[1][0] == mic.MIC_ERR_CORRUPT and out[2][0] == mic.MIC_ERR_CORRUPT
+    assert out[3][0] == 0 and np.array_equal(out[3][1], imgs[0])
+    # a too-small output buffer fails that job only
+    small = [np.empty(64, dtype=np.uint8), np.empty(mic.pics_bound(322, 256, 8), dtype=np.uint8)]
+    res = mic.compress_parallel_strips_batch(imgs[:2], 4095, 8, 2, outs=small)
+    assert res[0][0] == mic.MIC_ERR_CAPACITY and res[1][0] == 0
+    assert res[1][1].tobytes() == mico.pics_compress(imgs[1], 4095, 8, 2)[1]
+
+
+def test_pinned_buffers_take_the_direct_path(mic, mico, synth, gpu_ready):
+    img = synth.xr_like(cols=640, rows=512, depth=12, seed=3)
+    src = mic.host_alloc(img.nbytes, np.uint16).reshape(img.shape)
+    src[...] = img
+    dst = mic.host_alloc(mic.pics_bound(640, 512, 8))
+    try:
+        (st, blob), = mic.compress_parallel_strips_batch([src], 4095, 8, 2, outs=[dst])
+        assert st == 0 and blob.tobytes() == mico.pics_compress(img, 4095, 8, 2)[1]
+        back = mic.host_alloc(img.nbytes, np.uint16)
+        (st, px), = mic.decompress_parallel_strips_batch([blob], [(640, 512)], outs=[back])
+        assert st == 0 and np.array_equal(px, img)
+        mic.host_free(back)
+    finally:
+        mic.host_free(src); mic.host_free(dst)
+
+
+def test_sub_batch_pipeline_under_a_small_workspace(mic, mico, synth):
+    """A child process with an 8 MB workspace ceiling: every call walks several sub-batches (both staging halves, the packed-buffer
+    swap); results must not depend on the cut."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as e
+mic = e.load_package()
+import importlib
+synth = importlib.import_module("medical_image_codec_amd.synth")
+from oracle import mico
+imgs = [synth.xr_like(cols=322, rows=256, depth=12, seed=200 + i) for i in range(9)]
+res = mic.compress_parallel_strips_batch(imgs, 4095, 8, 2)
+files = []
+for img, (st, blob) in zip(imgs, res):
+    assert st == 0 and blob.tobytes() == mico.pics_compress(img, 4095, 8, 2)[1]
+    files.append(blob.tobytes())
+out = mic.decompress_parallel_strips_batch(files, [(322, 256)] * 9)
+for img, (st, px) in zip(imgs, out):
+    assert st == 0 and np.array_equal(px, img)
+jobs = mic.compress_batch(imgs, [4095] * 9, 4)
+for img, (st, blob, used) in zip(imgs, jobs):
+    rc, want = mico.compress_single_frame(img, 4095, 4)
+    assert st == 0 and blob == want
+back = mic.decompress_batch([b for _, b, _ in jobs], [(322, 256)] * 9)
+for img, (st, px) in zip(imgs, back):
+    assert st == 0 and np.array_equal(px, img)
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MIC_HIP_WS_BUDGET_MB="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_concurrent_callers_default_pool_and_sessions(mic, mico, synth, gpu_ready):
+    """Eight Python threads (ctypes releases the GIL) hammer the host-pointer entry points -- they share the pool of default sessions
+    -- while two more drive explicit sessions on the same device; every result is compared with the oracle."""
+    import torch
+    imgs = _images(synth, 6)
+    want_pics = [mico.pics_compress(i, 4095, 8, 2)[1] for i in imgs]
+    want_frame = [mico.compress_single_frame(i, 4095, 4)[1] for i in imgs]
+    ct = np.fromfile(os.path.join(ROOT, "tests", "golden", "CT_512_512_image.bin"), dtype="<u2").reshape(512, 512)
+    want_ct = mico.compress_single_frame(ct, int(ct.max()), 2)[1]
+    errors = []
+
+    def host_worker(k):
+        try:
+            for it in range(6):
+                i = (k + it) % len(imgs)
+                blob = mic.compress_parallel_strips(imgs[i], 322, 256, 4095, 8)
+                assert blob == want_pics[i], "pics bytes"
+                px, w, h = mic.decompress_parallel_strips(blob)
+                assert np.array_equal(px, imgs[i]), "pics pixels"
+                (st, fb, used), = mic.compress_batch([imgs[i]], [4095], 4)
+                assert st == 0 and fb == want_frame[i], "frame bytes"
+                if it % 3 == 0:
+                    assert mic.compress_single_frame(ct, 512, 512, int(ct.max()), 2) == want_ct, "ct bytes"
+                res = mic.compress_parallel_strips_batch([imgs[i], imgs[(i + 1) % len(imgs)]], 4095, 8, 2)
+                assert res[0][1].tobytes() == want_pics[i] and res[1][1].tobytes() == want_pics[(i + 1) % len(imgs)], "batch bytes"
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"host {k}: {e!r}")
+
+    def session_worker(k):
+        try:
+            d_px = torch.from_numpy(np.stack(imgs).view(np.int16)).cuda()
+            d_out = torch.empty_like(d_px)
+            units = [(f * 322 * 256 + y0 * 322, 322, 32, 4095, 2) for f in range(len(imgs)) for y0 in range(0, 256, 32)]
+            sess = mic.Session(len(units), 322 * 32)
+            cu = mic.Session.make_units(units)
+            for it in range(5):
+                sess.encode_enqueue(d_px.data_ptr(), cu)
+                d_blobs, offs, st, ns = sess.encode_finish()
+                assert (st == 0).all()
+                blobs = torch.empty(int(offs[-1]), dtype=torch.uint8, device="cuda")
+                mic.device_copy(blobs.data_ptr(), d_blobs, int(offs[-1]))
+                host = blobs.cpu().numpy()
+                for f in range(len(imgs)):                                     # strips of frame f = the payload of its PICS-8 file
+                    a, b = int(offs[f * 8]), int(offs[f * 8 + 8])
+                    assert host[a:b].tobytes() == want_pics[f][20 + 64:], "session bytes"
+                sess.decode_enqueue(d_blobs, offs, cu, d_out.data_ptr())
+                assert (sess.decode_finish() == 0).all()
+                assert torch.equal(d_out, d_px), "session pixels"
+            sess.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"session {k}: {e!r}")
+
+    threads = [threading.Thread(target=host_worker, args=(k,)) for k in range(8)] + \
+              [threading.Thread(target=session_worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
