@@ -113,7 +113,7 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
     if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
     int rc = s->ensure(n, max_px);
     if (rc) return rc;
-    s->h_units.assign((size_t)n, MicUnit{});
+    { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
@@ -125,7 +125,7 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
         u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
         if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8) || (units[i].nstates & ~(0xFF | MIC_HIP_PRED_GRAD))) return MIC_ERR_ARGS;
     }
-    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(n))) return rc;
     s->timer.reset(s->stream);
     mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
@@ -175,7 +175,7 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
     int rc = s->ensure(n, max_px);
     if (rc) return rc;
-    s->h_units.assign((size_t)n, MicUnit{});
+    { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
@@ -188,7 +188,7 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
         s->fill_workspace(u, i);
         u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
     }
-    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p);
@@ -289,12 +289,12 @@ int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, 
     if ((rc = s->ensure(1, px))) return rc;
     if ((rc = s->io_px.reserve(n * 2 + 64))) return rc;
     HIP_TRY(hipMemcpyAsync(s->io_px.p, symbols, n * 2, hipMemcpyHostToDevice, s->stream));
-    s->h_units.assign(1, MicUnit{});
+    { const int arc = s->h_units.assign(1, MicUnit{}); if (arc) return arc; }
     MicUnit &u = s->h_units[0];
     u.px_in = (const uint16_t *)s->io_px.p; u.w = (int32_t)n; u.h = 1; u.max_value = 0;
     u.nstates = (uint16_t)flavour; u.mode = 1; u.no_fallback = 1; u.req_tl = (uint32_t)table_log;
     s->fill_workspace(u, 0);
-    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
+    { const int urc = s->h_units.upload(s->units.p, 1, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(1))) return rc;
     mic_launch_encode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
@@ -334,12 +334,12 @@ int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t deco
     if ((rc = s->ensure(1, px))) return rc;
     if ((rc = s->io_comp.reserve(in_len + 64))) return rc;
     HIP_TRY(hipMemcpyAsync(s->io_comp.p, in, in_len, hipMemcpyHostToDevice, s->stream));
-    s->h_units.assign(1, MicUnit{});
+    { const int arc = s->h_units.assign(1, MicUnit{}); if (arc) return arc; }
     MicUnit &u = s->h_units[0];
     u.comp_in = (const uint8_t *)s->io_comp.p; u.comp_len = (uint32_t)in_len; u.w = 1; u.h = 1; u.mode = 1;
     s->fill_workspace(u, 0);
     u.tok_cap = (uint32_t)std::min<size_t>(out_cap, u.tok_cap);
-    HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit), hipMemcpyHostToDevice, s->stream));
+    { const int urc = s->h_units.upload(s->units.p, 1, s->stream); if (urc) return urc; }
     mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr, (int *)s->cls.p);
     HIP_TRY(hipGetLastError());
     s->n_last = 1;

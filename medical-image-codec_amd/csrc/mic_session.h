@@ -47,6 +47,39 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; gen++; }
 };
 
+// The host copy of a launch's unit descriptors, in pinned memory: the upload in front of every launch chain and the download of
+// the results behind it are DMA transfers that really are asynchronous (a pageable vector cost ~0.1 ms of staging each way per call).
+// Because the upload is asynchronous, the descriptors may not be rewritten while it is in flight: assign() waits for it.
+struct PinnedUnits {
+    MicUnit *p = nullptr; size_t cap = 0, n = 0;
+    hipEvent_t ev = nullptr; bool inflight = false;
+    int assign(size_t count, const MicUnit &v) {
+        if (inflight) { (void)hipEventSynchronize(ev); inflight = false; }
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = count + count / 4 + 16;
+            HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(MicUnit), hipHostMallocDefault));
+            cap = want;
+        }
+        for (size_t i = 0; i < count; i++) p[i] = v;
+        n = count;
+        return MIC_OK;
+    }
+    int upload(void *d_dst, size_t count, hipStream_t stream) {
+        HIP_TRY(hipMemcpyAsync(d_dst, p, sizeof(MicUnit) * count, hipMemcpyHostToDevice, stream));
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, stream));
+        inflight = true;
+        return MIC_OK;
+    }
+    MicUnit *data() { return p; }
+    MicUnit &operator[](size_t i) { return p[i]; }
+    const MicUnit &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    void release() { if (inflight) (void)hipEventSynchronize(ev); inflight = false; if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+};
+
 constexpr size_t kSym = 65536;
 
 inline size_t tok_cap_for(size_t px) { return 4 * px + 16; }
@@ -72,7 +105,7 @@ struct mic_hip_session {
     DevBuf wv_a, wv_b;                     // WaveletV2 coefficient planes (int32, two per frame of the batch)
     mic_hip_wsi_store *wsi = nullptr;      // mic_hip_session_wsi_*: coded planes of a slide, on the device
     DevBuf wsi_planes, wsi_stats; std::vector<DevBuf> wsi_pyr;
-    std::vector<MicUnit> h_units;
+    PinnedUnits h_units;
     std::vector<uint64_t> h_off;
     int n_last = 0;
     int variant = 0;                        // launch flags (MIC_VARIANT_GRAD is OR-ed in per call)
@@ -155,6 +188,7 @@ struct mic_hip_session {
         for (DevBuf &b : wsi_pyr) b.release();
         wsi_pyr.clear();
         if (wsi) { mic_wsi_store_free(wsi); wsi = nullptr; }
+        h_units.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         timer.destroy();

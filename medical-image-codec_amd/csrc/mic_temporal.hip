@@ -91,7 +91,7 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
         if ((rc = s->ensure(nb, npx))) return rc;
         HIP_TRY(hipMemcpyAsync(s->io_px.p, frames + (f0 - (size_t)lead) * npx, npx * 2 * (size_t)(nb + lead), hipMemcpyHostToDevice, s->stream));
         const uint16_t *d_first = (const uint16_t *)s->io_px.p + (size_t)lead * npx;   // frame f0 on the device
-        s->h_units.assign((size_t)nb, MicUnit{});
+        { const int arc = s->h_units.assign((size_t)nb, MicUnit{}); if (arc) return arc; }
         for (int i = 0; i < nb; i++) {
             MicUnit &u = s->h_units[(size_t)i];
             u.w = width; u.h = height; u.nstates = 2;
@@ -100,7 +100,7 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
             if (f0 == 0 && i == 0) { u.mode = 0; u.px_in = d_first; u.max_value = max_value; }
             else { u.mode = 2; u.nsym = (uint32_t)npx; u.max_value = 0; }
         }
-        HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
+        { const int urc = s->h_units.upload(s->units.p, (size_t)nb, s->stream); if (urc) return urc; }
         if ((rc = s->prepare_hist(nb))) return rc;
         const int r0 = f0 ? 0 : 1;                                        // first residual unit of the sub-batch
         if (nb > r0) {
@@ -150,7 +150,7 @@ int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_t
         if ((rc = s->io_px.reserve(npx * 2 * (size_t)(nb + 1)))) return rc;   // (grown before the carry below could be lost: sized for the first pass too)
         if ((rc = s->ensure(nb, npx))) return rc;
         size_t c0 = (size_t)-1, c1 = 0;                                   // byte range of the sub-batch's streams
-        s->h_units.assign((size_t)nb, MicUnit{});
+        { const int arc = s->h_units.assign((size_t)nb, MicUnit{}); if (arc) return arc; }
         for (int i = 0; i < nb; i++) {
             const size_t fi = f0 + (size_t)i;
             const size_t start = data_off + get_u32(c + 20 + fi * 8), bl = get_u32(c + 24 + fi * 8);
@@ -171,7 +171,7 @@ int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_t
             else u.mode = 3;                                             // FSE + RLE-of-symbols into u.sym
         }
         HIP_TRY(hipMemcpyAsync(s->io_comp.p, c + c0, c1 - c0, hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
+        { const int urc = s->h_units.upload(s->units.p, (size_t)nb, s->stream); if (urc) return urc; }
         HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)nb, s->stream));
         s->timer.reset(s->stream);
         mic_launch_decode((MicUnit *)s->units.p, nb, s->stream, s->variant, nullptr, (int *)s->cls.p);

@@ -744,13 +744,13 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
           hipLaunchKernelGGL(k_wv_fwd_cols, gc, dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n, nf);
           r = (r + 1) / 2; c = (c + 1) / 2;
       } }
-    s->h_units.assign((size_t)nf, MicUnit{});
+    { const int arc = s->h_units.assign((size_t)nf, MicUnit{}); if (arc) return arc; }
     for (int i = 0; i < nf; i++) {
         MicUnit &u = s->h_units[(size_t)i];
         u.w = 1; u.h = 1; u.nstates = 4; u.mode = 2; u.no_fallback = 1; // FSECompressU16FourState, no fallback (:344)
         s->fill_workspace(u, i);
     }
-    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    if (s->h_units.upload(s->units.p, (size_t)nf, s->stream) != MIC_OK) return done(MIC_ERR_DEVICE);
     if ((rc = s->prepare_hist(nf))) return done(rc);
     s->timer.mark("k_wv_symbols");
     {
@@ -787,13 +787,13 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     DevBuf &a = s->wv_a, &b = s->wv_b;
     if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
     auto done = [&](int code) { return code; };
-    s->h_units.assign((size_t)nf, MicUnit{});
+    { const int arc = s->h_units.assign((size_t)nf, MicUnit{}); if (arc) return arc; }
     for (int i = 0; i < nf; i++) {
         MicUnit &u = s->h_units[(size_t)i];
         u.comp_in = d_comp + offs[(size_t)i]; u.comp_len = (uint32_t)(offs[(size_t)i + 1] - offs[(size_t)i]); u.w = 1; u.h = 1; u.mode = 1; u.walk_mode = 1;
         s->fill_workspace(u, i);
     }
-    if (hipMemcpyAsync(s->units.p, s->h_units.data(), sizeof(MicUnit) * (size_t)nf, hipMemcpyHostToDevice, s->stream) != hipSuccess) return done(MIC_ERR_DEVICE);
+    if (s->h_units.upload(s->units.p, (size_t)nf, s->stream) != MIC_OK) return done(MIC_ERR_DEVICE);
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer, (int *)s->cls.p);

@@ -19,18 +19,24 @@ def _images(synth, n, w=322, h=256, depth=12):
 
 
 def test_pics_batch_equals_single_calls_and_the_oracle(mic, mico, synth, gpu_ready):
-    imgs = _images(synth, 5) + [synth.xr_like(cols=129, rows=77, depth=10, seed=7)]
+    # mixed shapes in one call; the last image is one the reference cannot code (a 1290-pixel strip of 10-bit noise has more
+    # distinct symbols than table slots: normalizeCount2 spins) -- the job fails, its neighbours do not
+    rng = np.random.default_rng(3)
+    ramp = ((np.arange(77 * 129).reshape(77, 129) // 3) % 900 + rng.integers(0, 3, (77, 129))).astype(np.uint16)
+    imgs = _images(synth, 5) + [ramp, synth.xr_like(cols=257, rows=200, depth=12, seed=9), synth.xr_like(cols=129, rows=77, depth=10, seed=7)]
     maxv = 4095
     res = mic.compress_parallel_strips_batch(imgs, maxv, 8, 2)
-    files = []
+    files, good = [], []
     for img, (st, blob) in zip(imgs, res):
-        assert st == 0
         rc, want = mico.pics_compress(img, maxv, 8, 2)
-        assert rc == 0 and blob.tobytes() == want
-        assert blob.tobytes() == mic.compress_parallel_strips(img, img.shape[1], img.shape[0], maxv, 8)
-        files.append(blob.tobytes())
-    out = mic.decompress_parallel_strips_batch(files, [(i.shape[1], i.shape[0]) for i in imgs])
-    for img, (st, px) in zip(imgs, out):
+        assert st == rc
+        if rc == 0:
+            assert blob.tobytes() == want
+            assert blob.tobytes() == mic.compress_parallel_strips(img, img.shape[1], img.shape[0], maxv, 8)
+            files.append(blob.tobytes()); good.append(img)
+    assert len(good) == 7
+    out = mic.decompress_parallel_strips_batch(files, [(i.shape[1], i.shape[0]) for i in good])
+    for img, (st, px) in zip(good, out):
         assert st == 0 and np.array_equal(px, img)
 
 
