@@ -279,6 +279,81 @@ def leg_wsi(mic, torch, synth, dev, steps, size=32768):
             "roofline": roofline_block(kmean, tile_rgb_bytes, nbytes)}
 
 
+def legs_multi_gpu(mic, torch, synth, par, dist, dev, rank, world, steps=5):
+    """BASELINE configs 4 and 5 as BASELINE.json words them ("sharded across 8 MI355X"), for N > 1: every rank codes its shard
+    (frames of the 512^3 stack: multiframecompress.go:201-203; a band of the 32768^2 slide: wsicompress.go:126-145), rank 0
+    assembles the container.  `coding` = the slowest rank's own encode (+ decode) of its shard; `container_assembly` = everything
+    the distributed call adds to it: sizes all-gather, device-to-device gather of the streams over RCCL, the top pyramid levels and the
+    header on rank 0.  min / median over `steps` runs."""
+    def barrier():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    def tmax(v):
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def stats(xs):
+        return {"min_ms": round(min(xs) * 1e3, 3), "median_ms": round(float(np.median(xs)) * 1e3, 3)}
+
+    out = {}
+    # ---- config 4: MIC2 independent mode, 512 frames of 512 x 512, frames sharded
+    n, sz = 512, 512
+    lo, hi = par.shard_range(n, world, rank)
+    stack = synth.ct_stack(n, sz, 12, seed=3)[lo:hi]
+    d_px = torch.from_numpy(np.ascontiguousarray(stack).view(np.int16)).to(dev)
+    units = [((i - lo) * sz * sz if lo <= i < hi else 0, sz, sz, 4095, 2) for i in range(n)]
+    sess = mic.Session(max(hi - lo, 1), sz * sz, device=dev.index)
+    enc, dec = par.session_codec(mic, sess, d_px, units)
+    t_code, t_all, t_dcode, t_dall = [], [], [], []
+    mic2 = None
+    for it in range(steps + 1):
+        barrier(); t0 = time.perf_counter(); blobs, sizes = enc(lo, hi); torch.cuda.synchronize(); a = tmax(time.perf_counter() - t0)
+        barrier(); t0 = time.perf_counter(); mic2 = par.dist_compress_multi_frame(enc, sz, sz, n); barrier(); b = tmax(time.perf_counter() - t0)
+        loffs = np.concatenate([[0], np.cumsum(sizes.cpu().numpy())]).astype(np.int64)
+        barrier(); t0 = time.perf_counter(); px = dec(lo, hi, blobs, loffs, sz, sz); torch.cuda.synchronize(); c = tmax(time.perf_counter() - t0)
+        barrier(); t0 = time.perf_counter(); _, _, px2 = par.dist_decompress_multi_frame(dec, mic2, device=dev); barrier(); d = tmax(time.perf_counter() - t0)
+        assert torch.equal(px, d_px.view(px.shape)) and torch.equal(px2, d_px.view(px2.shape)), "MIC2 shard round trip differs"
+        if it:
+            t_code.append(a); t_all.append(b); t_dcode.append(c); t_dall.append(d)
+    sess.close()
+    raw = n * sz * sz * 2
+    out["config4_mic2_512cubed"] = {
+        "workload": f"MIC2 independent mode, 512 x 512 x 512 CT-like stack, {hi - lo} frames per rank on {world} ranks",
+        "value": round(raw / (min(t_code) + min(t_dcode)) / 1e9, 4), "unit": "GB/s (coding of the shards, slowest rank)",
+        "encode_coding": stats(t_code), "encode_with_assembly": stats(t_all), "decode_coding": stats(t_dcode), "decode_with_scatter": stats(t_dall),
+        "container_assembly_ms": round((min(t_all) - min(t_code)) * 1e3, 3),
+        "ratio": round(raw / len(mic2), 4) if mic2 else None,
+        "note": "512 frames are 512 entropy chains: 64 per GPU on 8 GPUs is a quarter chain per CU -- latency-bound, the configuration is too small for the node"}
+    del d_px
+    # ---- config 5: MIC3, 32768 x 32768 RGB, bands of tile rows
+    size = 32768
+    levels = par.wsi_levels(size, size, 256, 256, 0)
+    K, bands = par.wsi_band_plan(size, 256, len(levels), world)
+    y0, y1 = bands[rank]
+    band = torch.from_numpy(synth.wsi_slide_band(size, size, y0, y1, seed=4)).to(dev)
+    sess = mic.Session(1, 256 * 256, device=dev.index)
+    enc_slide = par.session_wsi_codec(mic, sess)
+    t_code, t_all = [], []
+    f = None
+    for it in range(max(2, steps // 2) + 1):
+        barrier(); t0 = time.perf_counter()
+        if y1 > y0:
+            enc_slide(band, min(K + 1, len(levels)))
+        torch.cuda.synchronize(); a = tmax(time.perf_counter() - t0)
+        barrier(); t0 = time.perf_counter(); f = par.dist_compress_wsi(enc_slide, band, size, size); barrier(); b = tmax(time.perf_counter() - t0)
+        if it:
+            t_code.append(a); t_all.append(b)
+    sess.close()
+    out["config5_mic3_wsi_32768"] = {
+        "workload": f"MIC3 encode of a {size}x{size} RGB slide in bands of {256 << K} rows (levels 0..{K} per band, the rest on rank 0), {world} ranks",
+        "value": round(size * size * 3 / min(t_code) / 1e9, 4), "unit": "GB/s of level-0 RGB (coding of the bands, slowest rank)",
+        "encode_coding": stats(t_code), "encode_with_assembly": stats(t_all),
+        "container_assembly_ms": round((min(t_all) - min(t_code)) * 1e3, 3),
+        "compressed_bytes": len(f) if f else None}
+    return out
+
+
 def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
     """SURVEY.md §8(d) "Timing", the second figure: host buffers in, host buffers out, through the C ABI's batch entry points
     (mic_hip_pics_compress_batch / _decompress_batch -- what a cgo caller uses), for ordinary (pageable) numpy buffers and for
@@ -487,6 +562,20 @@ def main():
             "container_assembly": assembly,
         }
     sess.close()
+
+    if world == 1 and os.environ.get("MIC_BENCH_REHEARSE_MULTI"):       # the N > 1 legs on one rank (nccl, world size 1): a rehearsal of the code path
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        out["legs_multi_gpu_rehearsal"] = legs_multi_gpu(mic, torch, synth, par, dist, dev, 0, 1, steps=2)
+        dist.destroy_process_group()
+        dist = None
+    if world > 1 and not args.no_legs:
+        try:
+            out["legs_multi_gpu"] = legs_multi_gpu(mic, torch, synth, par, dist, dev, rank, world)
+        except Exception as e:  # noqa: BLE001 -- the headline line must come out whatever a leg does
+            out["legs_multi_gpu"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     if world == 1 and not args.no_e2e and not args.legs_only:
         out["end_to_end"] = leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev)

@@ -368,6 +368,10 @@ int mic_hip_session_wavelet_v2_decode(mic_hip_session *s, const uint8_t *d_strea
 int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int width, int height, int channels, int bits_per_sample,
                                int tile_w, int tile_h, int levels, uint64_t *total_tiles, uint64_t *compressed_bytes);
 int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len);
+/* The same store as the container's PAYLOAD on the device -- every tile blob in container order, put together by a kernel:
+ * *d_payload (valid until the session's next wsi call), its size, and tile_lens[cap >= total tiles] (host).  What a writer that
+ * gathers several GPUs' tiles moves device to device; header, level table and tile index (wsiformat.go:99-165) are its own. */
+int mic_hip_session_wsi_payload(mic_hip_session *s, const uint8_t **d_payload, uint64_t *payload_bytes, uint64_t *tile_lens, size_t cap);
 int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_pixels_out, size_t out_cap);
 int mic_hip_session_wsi_levels(mic_hip_session *s, int *levels, int *widths, int *heights, int cap);
 /* Enables (1) / disables (0) per-kernel HIP-event timing of the enqueue calls. */

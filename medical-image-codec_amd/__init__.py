@@ -109,7 +109,7 @@ ABI_SYMBOLS = [
     "mic_hip_session_create", "mic_hip_session_create_on", "mic_hip_session_device", "mic_hip_session_destroy", "mic_hip_session_stream",
     "mic_hip_device_copy",
     "mic_hip_session_wavelet_v2_encode", "mic_hip_session_wavelet_v2_decode",
-    "mic_hip_session_wsi_encode", "mic_hip_session_wsi_write", "mic_hip_session_wsi_decode_level", "mic_hip_session_wsi_levels",
+    "mic_hip_session_wsi_encode", "mic_hip_session_wsi_write", "mic_hip_session_wsi_payload", "mic_hip_session_wsi_decode_level", "mic_hip_session_wsi_levels",
     "mic_hip_session_encode", "mic_hip_session_decode",
     "mic_hip_session_encode_enqueue", "mic_hip_session_encode_finish",
     "mic_hip_session_decode_enqueue", "mic_hip_session_decode_finish",
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
                                                     C.c_void_p, C.POINTER(C.c_int32)]
     L.mic_hip_session_wsi_encode.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mic_hip_session_wsi_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_session_wsi_payload.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
     L.mic_hip_session_wsi_decode_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.mic_hip_session_wsi_levels.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.mic_hip_session_destroy.argtypes = [C.c_void_p]
@@ -841,6 +842,14 @@ class Session:
         if rc:
             _raise(rc, "session_wsi_write")
         return out[: n.value].tobytes()
+
+    def wsi_payload(self, total_tiles: int) -> Tuple[int, int, np.ndarray]:
+        """-> (device address of the container's payload, its size, tile lengths in container order); valid until the next wsi call"""
+        d = C.c_void_p(0); nb = C.c_uint64(0); lens = np.zeros(max(total_tiles, 1), dtype=np.uint64)
+        rc = lib().mic_hip_session_wsi_payload(self._h, C.byref(d), C.byref(nb), lens.ctypes.data, lens.size)
+        if rc:
+            _raise(rc, "session_wsi_payload")
+        return d.value, nb.value, lens[:total_tiles].astype(np.int64)
 
     def wsi_levels(self) -> List[Tuple[int, int]]:
         n = C.c_int(0); w = (C.c_int * 32)(); h = (C.c_int * 32)()

@@ -10,6 +10,7 @@
 // the requested tiles, then inverse transform + crop on the device.
 #include "mic_session.h"
 
+static constexpr size_t kMaxGridX = 0x7FFFFFFF;
 static constexpr size_t kMaxGridY = 65535;   // HIP grid limit in y and z: launches that put tiles there take at most this many per sub-batch
 
 namespace {
@@ -209,7 +210,7 @@ int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::v
     const size_t ntile = tiles.size();
     const size_t P = (size_t)m.planes(), bpp = m.bpp();
     // per-tile chunking keeps the unit workspace bounded
-    const size_t per = std::min<size_t>(kMaxGridY, std::max<size_t>(1, kWorkspaceBudget / (P * unit_ws_bytes(npx))));   // (tiles are a launch's grid y)
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, kWorkspaceBudget / (P * unit_ws_bytes(npx))));   // (tiles are a launch's grid y)
     struct Bufs { DevBuf planes, d_place, d_out; ~Bufs() { planes.release(); d_place.release(); d_out.release(); } } bufs;   // freed on every return path
     DevBuf &planes = bufs.planes, &d_place = bufs.d_place, &d_out = bufs.d_out;
     int rc;
@@ -301,7 +302,7 @@ int compress_level_tiles(mic_hip_session *s, const void *d_img, const Level &L, 
                          std::vector<uint8_t> *blobs_out) {
     const size_t P = (size_t)fmt.planes();
     const size_t npx = (size_t)tile_w * tile_h;
-    const size_t per = std::min<size_t>(kMaxGridY, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2))));
     DevBuf planes, stats;
     int rc = MIC_OK;
     const size_t ntl = (size_t)L.tx * L.ty;
@@ -693,7 +694,7 @@ namespace {
 int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_img, const Level &L) {
     const Mic3 &fmt = W.fmt;
     const size_t P = (size_t)fmt.planes(), npx = (size_t)fmt.tw * fmt.th;
-    const size_t per = std::min<size_t>(kMaxGridY, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
     DevBuf &planes = s->wsi_planes, &stats = s->wsi_stats;
     const size_t ntl = (size_t)L.tx * L.ty;
     int rc;
@@ -812,23 +813,97 @@ int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int 
 
 // WriteMIC3 (wsiformat.go:99-165) around the store: header, level table, tile table, tile blobs ([Ylen][Colen][Cglen] + planes,
 // wsicompress.go:341-363; grey: the bare plane).  One device-to-host copy of the store's bytes.
+// The container's payload -- every tile blob, in container order -- is put together on the DEVICE: the plane records are host
+// data (mode, constant, offset and length of each coded plane), so the host lays the tiles out (a prefix sum over 16 bytes per
+// plane) and one kernel copies every plane's bytes from the store to its place, with the mode byte in front and, for RGB, the
+// tile's three plane lengths (compressTileBlob, wsicompress.go:334-364).  WriteMIC3 then is one transfer of the payload straight
+// into the caller's buffer behind the header and the tile index; a multi-GPU writer gathers the payload device to device.
+struct WsiRec { uint64_t src, dst; uint32_t len; uint32_t mode_value; };          // mode_value = mode | value << 8
+__global__ void __launch_bounds__(256) k_wsi_assemble(const WsiRec *recs, int P, const uint8_t *store, uint8_t *payload) {
+    const size_t t = blockIdx.x;
+    typedef uint32_t wv4 __attribute__((ext_vector_type(4)));
+    typedef wv4 WQ __attribute__((aligned(1)));
+    for (int p = 0; p < P; p++) {
+        const WsiRec r = recs[t * (size_t)P + (size_t)p];
+        const uint32_t mode = r.mode_value & 0xFFu, value = r.mode_value >> 8;
+        uint8_t *d = payload + r.dst;
+        const uint32_t plen = mode == 0 ? 1u : mode == 1 ? 3u : 1u + r.len;
+        if (threadIdx.x == 0) {
+            d[0] = (uint8_t)mode;
+            if (mode == 1) { d[1] = (uint8_t)value; d[2] = (uint8_t)(value >> 8); }
+            if (P == 3) {                                                               // [Y_len][Co_len][Cg_len], u32 LE, in front of the tile's planes
+                uint8_t *h = payload + recs[t * 3].dst - 12 + 4 * p;
+                h[0] = (uint8_t)plen; h[1] = (uint8_t)(plen >> 8); h[2] = (uint8_t)(plen >> 16); h[3] = (uint8_t)(plen >> 24);
+            }
+        }
+        if (mode >= 2) {
+            const uint8_t *sp = store + r.src; uint8_t *dp = d + 1;
+            const uint32_t nv = r.len / 16;
+            for (uint32_t i = threadIdx.x; i < nv; i += 256) *(WQ *)(dp + (size_t)i * 16) = *(const WQ *)(sp + (size_t)i * 16);
+            if (threadIdx.x < (r.len & 15u)) dp[(size_t)nv * 16 + threadIdx.x] = sp[(size_t)nv * 16 + threadIdx.x];
+        }
+    }
+}
+
+// lays the payload out and builds it in s->wsi_payload; tlen[t] = bytes of tile t, *total = their sum
+static int wsi_assemble(mic_hip_session *s, std::vector<uint64_t> &tlen, uint64_t *total_out) {
+    mic_hip_wsi_store &W = *s->wsi;
+    const size_t P = (size_t)W.fmt.planes();
+    std::vector<WsiRec> recs(W.total_tiles * P);
+    tlen.assign(W.total_tiles, 0);
+    uint64_t off = 0;
+    for (size_t t = 0; t < W.total_tiles; t++) {
+        const uint64_t t0 = off;
+        if (P == 3) off += 12;
+        for (size_t p = 0; p < P; p++) {
+            const WsiPlane &wp = W.planes[t * P + p];
+            const uint64_t n = wp.mode == 0 ? 1 : wp.mode == 1 ? 3 : 1 + (uint64_t)wp.len;
+            recs[t * P + p] = WsiRec{ wp.off, off, wp.mode >= 2 ? wp.len : 0u, (uint32_t)wp.mode | ((uint32_t)wp.value << 8) };
+            off += n;
+        }
+        tlen[t] = off - t0;
+    }
+    *total_out = off;
+    int rc;
+    if ((rc = s->wsi_payload.reserve((size_t)off + 64))) return rc;
+    if ((rc = s->wsi_recs.reserve(recs.size() * sizeof(WsiRec) + 64))) return rc;
+    if (!recs.empty()) {
+        HIP_TRY(hipMemcpyAsync(s->wsi_recs.p, recs.data(), recs.size() * sizeof(WsiRec), hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_wsi_assemble, dim3((unsigned)W.total_tiles), dim3(256), 0, s->stream, (const WsiRec *)s->wsi_recs.p, (int)P,
+                           (const uint8_t *)W.bytes.p, (uint8_t *)s->wsi_payload.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));                                       // (recs is a stack-scope vector)
+    }
+    return MIC_OK;
+}
+
+// The store as the container's payload, on the device: *d_payload (valid until the session's next wsi call), its size, and the
+// byte length of every tile in container order (tile_lens[cap >= total tiles], host).  What a multi-GPU writer gathers.
+int mic_hip_session_wsi_payload(mic_hip_session *s, const uint8_t **d_payload, uint64_t *payload_bytes, uint64_t *tile_lens, size_t cap) {
+    if (!s || !d_payload || !payload_bytes || !tile_lens || !s->wsi) return MIC_ERR_ARGS;
+    int rc = s->activate();
+    if (rc) return rc;
+    if (cap < s->wsi->total_tiles) return MIC_ERR_CAPACITY;
+    if ((size_t)kMaxGridX < s->wsi->total_tiles) return MIC_ERR_UNSUPPORTED;
+    std::vector<uint64_t> tlen; uint64_t total = 0;
+    if ((rc = wsi_assemble(s, tlen, &total))) return rc;
+    for (size_t t = 0; t < tlen.size(); t++) tile_lens[t] = tlen[t];
+    *d_payload = (const uint8_t *)s->wsi_payload.p; *payload_bytes = total;
+    return MIC_OK;
+}
+
 int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!s || !out || !out_len || !s->wsi) return MIC_ERR_ARGS;
     int rc = s->activate();
     if (rc) return rc;
     mic_hip_wsi_store &W = *s->wsi;
-    const size_t P = (size_t)W.fmt.planes(), nlev = W.lv.size();
+    if ((size_t)kMaxGridX < W.total_tiles) return MIC_ERR_UNSUPPORTED;
+    const size_t nlev = W.lv.size();
     const size_t hdr = 48 + 20 * nlev + 16 * W.total_tiles;
-    std::vector<uint8_t> host(W.used + 16);
-    if (W.used) HIP_TRY(hipMemcpy(host.data(), W.bytes.p, W.used, hipMemcpyDeviceToHost));
-    size_t total = 0;
-    std::vector<uint64_t> tlen(W.total_tiles);
-    for (size_t t = 0; t < W.total_tiles; t++) {
-        uint64_t n = (P == 3) ? 12 : 0;
-        for (size_t p = 0; p < P; p++) { const WsiPlane &wp = W.planes[t * P + p]; n += wp.mode == 0 ? 1 : wp.mode == 1 ? 3 : 1 + (uint64_t)wp.len; }
-        tlen[t] = n; total += n;
-    }
+    std::vector<uint64_t> tlen; uint64_t total = 0;
+    if ((rc = wsi_assemble(s, tlen, &total))) return rc;
     if (out_cap < hdr + total) return MIC_ERR_CAPACITY;
+    if ((rc = micapi::host_copy(s->device, s->wsi_payload.p, out + hdr, (size_t)total, false))) return rc;   // (the header is written meanwhile? no: after -- it is 0.4 MB)
     memset(out, 0, hdr);
     memcpy(out, "MIC3", 4); put_u32(out + 4, 1); put_u32(out + 8, (uint32_t)W.fmt.w); put_u32(out + 12, (uint32_t)W.fmt.h);
     put_u32(out + 16, (uint32_t)W.fmt.tw); put_u32(out + 20, (uint32_t)W.fmt.th);
@@ -840,22 +915,13 @@ int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, 
         put_u32(ld, (uint32_t)W.lv[i].w); put_u32(ld + 4, (uint32_t)W.lv[i].h); put_u32(ld + 8, (uint32_t)W.lv[i].tx);
         put_u32(ld + 12, (uint32_t)W.lv[i].ty); put_u32(ld + 16, (uint32_t)W.lv[i].first);
     }
-    size_t off = 0;
+    uint64_t off = 0;
     for (size_t t = 0; t < W.total_tiles; t++) {
         uint8_t *e = out + 48 + 20 * nlev + 16 * t;
-        put_u64(e, (uint64_t)off); put_u64(e + 8, tlen[t]);
-        uint8_t *tb = out + hdr + off, *w = tb + (P == 3 ? 12 : 0);
-        for (size_t p = 0; p < P; p++) {
-            const WsiPlane &wp = W.planes[t * P + p];
-            uint8_t *w0 = w;
-            if (wp.mode == 0) *w++ = 0;
-            else if (wp.mode == 1) { *w++ = 1; *w++ = (uint8_t)wp.value; *w++ = (uint8_t)(wp.value >> 8); }
-            else { *w++ = wp.mode; memcpy(w, host.data() + wp.off, wp.len); w += wp.len; }
-            if (P == 3) put_u32(tb + 4 * p, (uint32_t)(w - w0));
-        }
+        put_u64(e, off); put_u64(e + 8, tlen[t]);
         off += tlen[t];
     }
-    *out_len = hdr + total;
+    *out_len = hdr + (size_t)total;
     return MIC_OK;
 }
 
@@ -871,7 +937,7 @@ int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_p
     const size_t P = (size_t)m.planes(), bpp = m.bpp(), npx = (size_t)m.tw * m.th;
     if ((size_t)L.w * L.h * bpp > out_cap) return MIC_ERR_CAPACITY;
     const size_t ntl = (size_t)L.tx * L.ty;
-    const size_t per = std::min<size_t>(kMaxGridY, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
     DevBuf &planes = s->wsi_planes, &aux = s->wsi_stats;
     for (size_t t0 = 0; t0 < ntl; t0 += per) {
         const size_t nt = std::min(per, ntl - t0);

@@ -368,6 +368,15 @@ inline void pics_geometry(int height, int num_strips, int &strip_h, int &actual)
 
 }  // namespace
 
+namespace micapi {
+int host_copy(int device, void *dev, void *host, size_t bytes, bool to_device) {
+    IoReq req;
+    const int rc = io_submit(req, device, dev, host, bytes, to_device);
+    const int r2 = req.wait();
+    return rc ? rc : r2;
+}
+}  // namespace micapi
+
 // ================================================================================ C ABI
 extern "C" {
 

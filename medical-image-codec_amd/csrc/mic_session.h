@@ -104,7 +104,7 @@ struct mic_hip_session {
     DevBuf io_px2, io_comp2, packed2;      // their second halves: sub-batch k + 1 comes up while k is coded and k - 1 goes down (mic_host_io.hip)
     DevBuf wv_a, wv_b;                     // WaveletV2 coefficient planes (int32, two per frame of the batch)
     mic_hip_wsi_store *wsi = nullptr;      // mic_hip_session_wsi_*: coded planes of a slide, on the device
-    DevBuf wsi_planes, wsi_stats; std::vector<DevBuf> wsi_pyr;
+    DevBuf wsi_planes, wsi_stats, wsi_payload, wsi_recs; std::vector<DevBuf> wsi_pyr;
     PinnedUnits h_units;
     std::vector<uint64_t> h_off;
     int n_last = 0;
@@ -177,13 +177,13 @@ struct mic_hip_session {
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     size_t reserved_bytes() const {
-        const DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
+        const DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats, &wsi_payload, &wsi_recs };
         size_t t = 0;
         for (const DevBuf *b : all) t += b->cap;
         return t;
     }
     void release() {
-        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats };
+        DevBuf *all[] = { &units, &cls, &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &packed, &offsets, &seg, &sym, &flags, &io_px, &io_comp, &io_px2, &io_comp2, &packed2, &wv_a, &wv_b, &wsi_planes, &wsi_stats, &wsi_payload, &wsi_recs };
         for (DevBuf *b : all) b->release();
         for (DevBuf &b : wsi_pyr) b.release();
         wsi_pyr.clear();
@@ -221,5 +221,8 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
                            uint8_t *out, size_t out_cap, size_t *out_len);
 int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_total, int n, uint16_t *frames_out);
 size_t workspace_budget();        // per-call workspace ceiling (mic_api.hip)
+// one blocking host <-> device copy through the transfer engine of mic_host_io.hip (pinned host memory: DMA in place; ordinary
+// memory: staged through pinned slots by the worker threads).  The device side must be ready / is complete on return.
+int host_copy(int device, void *dev, void *host, size_t bytes, bool to_device);
 #define kWorkspaceBudget (micapi::workspace_budget())
 }  // namespace micapi

@@ -4,7 +4,7 @@ Strips (parallelstrips.go:77-93), MIC2 frames (multiframecompress.go:201-203) an
 so a rank codes a contiguous range of the units and the only cross-rank traffic is the assembly of a container on one rank:
 an all-gather of the per-unit compressed sizes (8 bytes per unit) and a gather of the packed blobs -- point-to-point sends into
 the slices of ONE buffer on the destination rank, exact sizes, no padding.  On the `nccl` backend (= RCCL) every tensor here is a
-device tensor, so the blobs go GPU to GPU over xGMI and never touch the host; on `gloo` (the CPU tests) the same code moves CPU
+device tensor, so the blobs -- MIC3 tile payloads included -- go GPU to GPU over xGMI and never touch the host; on `gloo` (the CPU tests) the same code moves CPU
 tensors.  Decode is the mirror image: the owner of a container scatters each rank's slice, every rank decodes its units.
 No all-reduce, no collective inside the codec.  The codec is injected (a callable), so the CPU tests drive the plumbing with
 gloo and the oracle, and the GPU tests / bench.py with a mic_hip session.
@@ -334,8 +334,10 @@ def downsample2x(img):
 def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int = 256, tile_h: int = 256, levels_req: int = 0,
                       channels: int = 3, bits: int = 8, group=None) -> Optional[bytes]:
     """CompressWSI over the ranks.  band: this rank's rows of the slide (wsi_band_plan's (y0, y1)) as a (rows, width[, channels])
-    tensor on the backend's device; encode_slide(image tensor, levels) -> the MIC3 file of that image as bytes (the injected
-    codec: a mic_hip session on a GPU, the oracle in the CPU tests).  Rank 0 returns the slide's MIC3 file, the others None."""
+    tensor on the backend's device; encode_slide(image tensor, levels) -> (payload: uint8 tensor on the backend's device holding
+    every tile blob of that image in container order, tile sizes: int64 numpy array, level table [(w, h, tiles across, tiles
+    down)]) -- the injected codec: a mic_hip session on a GPU (session_wsi_codec: the payload never leaves the device), the
+    oracle in the CPU tests (slide_codec_from_bytes).  Rank 0 returns the slide's MIC3 file, the others None."""
     import torch
     dist, world, rank = _dist(group)
     levels = wsi_levels(width, height, tile_w, tile_h, levels_req)
@@ -349,15 +351,13 @@ def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int =
     tiles_of = [[((rows + tile_h - 1) // tile_h) * levels[k][2] if rows > 0 and k < L else 0 for k, rows in enumerate(nl)] for nl in nloc]
     payload, sizes = torch.empty(0, dtype=torch.uint8, device=dev), torch.empty(0, dtype=torch.int64, device=dev)
     if y1 > y0:
-        f = encode_slide(band, min(K + 1, L))
-        lv, sz, d0 = parse_mic3(f)
+        payload, sz, lv = encode_slide(band, min(K + 1, L))
         assert [t[2] * t[3] for t in lv] == [t for t in tiles_of[rank] if t], (lv, tiles_of[rank])
-        payload = torch.from_numpy(np.frombuffer(f, dtype=np.uint8, offset=d0).copy()).to(dev)
-        sizes = torch.from_numpy(sz).to(dev)
+        sizes = torch.from_numpy(np.asarray(sz, dtype=np.int64)).to(dev)
     starts = np.concatenate([[0], np.cumsum([sum(t) for t in tiles_of])]).astype(np.int64)
     allb, offs = _gather_by_shards(payload, sizes, [(int(starts[r]), int(starts[r + 1])) for r in range(world)], group)
     # 2. the rows of level K + 1 go to rank 0, which codes the top of the pyramid
-    top_file = None
+    top = None
     if L > K + 1:
         t = band
         for _ in range(K + 1):
@@ -369,31 +369,52 @@ def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int =
         if rank == 0:
             assert topb.numel() == sum(nrows) * row_bytes == levels[K + 1][1] * row_bytes, (topb.numel(), nrows, levels[K + 1])
             shape = (levels[K + 1][1], levels[K + 1][0]) + ((channels,) if channels > 1 else ())
-            top_file = encode_slide(topb.view(band.dtype).reshape(shape), L - K - 1)
+            top = encode_slide(topb.view(band.dtype).reshape(shape), L - K - 1)
     if rank != 0:
         return None
-    # 3. the container: level by level, band by band
-    host = allb.cpu().numpy()
+    # 3. the container: level by level, band by band (slices of the gathered device buffer, one concatenation, one copy to the host)
     pieces, out_sizes = [], []
     for k in range(min(K + 1, L)):
         for r in range(world):
             t0 = int(starts[r]) + sum(tiles_of[r][:k]); t1 = t0 + tiles_of[r][k]
-            pieces.append(host[int(offs[t0]): int(offs[t1])]); out_sizes.extend(np.diff(offs[t0: t1 + 1]).tolist())
-    if top_file is not None:
-        lv, sz, d0 = parse_mic3(top_file)
-        assert [(a, b, c, d) for a, b, c, d, _ in lv] == list(levels[K + 1:]), (lv, levels[K + 1:])
-        pieces.append(np.frombuffer(top_file, dtype=np.uint8, offset=d0)); out_sizes.extend(sz.tolist())
+            pieces.append(allb[int(offs[t0]): int(offs[t1])]); out_sizes.extend(np.diff(offs[t0: t1 + 1]).tolist())
+    if top is not None:
+        tp, tsz, tlv = top
+        assert [tuple(a) for a in tlv] == [tuple(a) for a in levels[K + 1:]], (tlv, levels[K + 1:])
+        pieces.append(tp); out_sizes.extend(np.asarray(tsz).tolist())
     assert len(out_sizes) == sum(a[2] * a[3] for a in levels)
-    return mic3_header(width, height, tile_w, tile_h, channels, bits, levels, out_sizes) + b"".join(p.tobytes() for p in pieces)
+    body = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=dev)
+    return mic3_header(width, height, tile_w, tile_h, channels, bits, levels, out_sizes) + body.cpu().numpy().tobytes()
+
+
+def slide_codec_from_bytes(encode_file, device="cpu"):
+    """encode_slide for dist_compress_wsi from a function that returns a MIC3 FILE as bytes (the oracle in the CPU tests)"""
+    import torch
+
+    def encode_slide(img, levels: int):
+        f = encode_file(img, levels)
+        lv, sz, d0 = parse_mic3(f)
+        payload = torch.from_numpy(np.frombuffer(f, dtype=np.uint8, offset=d0).copy()).to(device)
+        return payload, sz, [(a, b, c, d) for a, b, c, d, _ in lv]
+    return encode_slide
 
 
 def session_wsi_codec(mic, sess, tile_w: int = 256, tile_h: int = 256):
     """encode_slide for dist_compress_wsi on a GPU: the band (a device tensor) goes through the session's device-resident MIC3
-    encoder; the band's container is written on the host (assembly, outside the coding path)"""
-    def encode_slide(img, levels: int) -> bytes:
+    encoder, a kernel lays the coded planes out as the container's payload (mic_hip_session_wsi_payload), and that payload is
+    handed on as a device tensor: nothing but the tile sizes touches the host"""
+    import torch
+
+    def encode_slide(img, levels: int):
         img = img.contiguous()
         ch = img.shape[2] if img.dim() == 3 else 1
         bits = 16 if img.element_size() == 2 else 8
-        sess.wsi_encode(img.data_ptr(), int(img.shape[1]), int(img.shape[0]), ch, bits, tile_w, tile_h, levels)
-        return sess.wsi_write()
+        w, h = int(img.shape[1]), int(img.shape[0])
+        tiles, _ = sess.wsi_encode(img.data_ptr(), w, h, ch, bits, tile_w, tile_h, levels)
+        d_payload, nbytes, lens = sess.wsi_payload(tiles)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        if nbytes:
+            mic.device_copy(out.data_ptr(), d_payload, nbytes)
+        lv = [(lw, lh, (lw + tile_w - 1) // tile_w, (lh + tile_h - 1) // tile_h) for lw, lh in sess.wsi_levels()]
+        return out, lens, lv
     return encode_slide

@@ -1,4 +1,4 @@
-"""World-size-2 gloo tests (CPU) of the multi-GPU plumbing: static unit sharding, size all-gather, point-to-point blob gather /
+"""World-size-2 and -4 gloo tests (CPU) of the multi-GPU plumbing: static unit sharding, size all-gather, point-to-point blob gather /
 scatter, MIC2 and PICS assembly, sharded decode.  The codec is a stand-in here (the oracle, on CPU tensors), exactly as the
 mic_hip session is injected on a GPU node (parallel.session_codec; tests/test_gpu_parity.py runs that on one rank with `nccl`);
 the assembled files must equal the single-process oracle's."""
@@ -64,14 +64,18 @@ def _worker(rank, world, port, stack, q):
         H, W = slide.shape[:2]
         lv = par.wsi_levels(W, H, 256, 256, 0)
         K, bands = par.wsi_band_plan(H, 256, len(lv), world)
-        assert len(lv) == 4 and K == 2 and bands == [(0, 1024), (1024, 1300)]
+        assert len(lv) == 4
+        if world == 2:
+            assert K == 2 and bands == [(0, 1024), (1024, 1300)]
+        if world == 4:                                                           # (K changes with the world size: bands of one tile row)
+            assert K == 0 and bands == [(0, 256), (256, 768), (768, 1024), (1024, 1300)]
 
-        def encode_slide(img, levels):
+        def encode_file(img, levels):
             rc, f = mico.wsi_compress(np.ascontiguousarray(img.numpy()), 256, 256, levels)
             assert rc == 0
             return f
         y0, y1 = bands[rank]
-        mic3 = par.dist_compress_wsi(encode_slide, torch.from_numpy(slide[y0:y1].copy()), W, H)
+        mic3 = par.dist_compress_wsi(par.slide_codec_from_bytes(encode_file), torch.from_numpy(slide[y0:y1].copy()), W, H)
         if rank == 0:
             q.put((mic2, pics, mic3))
     finally:
@@ -95,14 +99,15 @@ def test_shard_range_is_a_partition(mic):
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
 
 
-def test_two_rank_mic2_and_pics_assembly_match_single_process(mico, synth):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_mic2_pics_and_mic3_assembly_match_single_process(mico, synth, world):
     stack = np.stack([synth.xr_like(cols=128, rows=128, depth=12, seed=80 + i) for i in range(5)])   # (every strip codes: no constant one)
     rc, want = mico.mic2_compress(stack, 4095, False)
     assert rc == 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, stack, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, stack, q)) for r in range(world)]
     for p in procs:
         p.start()
     mic2, pics, mic3 = q.get(timeout=120)
