@@ -835,13 +835,15 @@ class Session:
         self._wsi_bytes = cb.value
         return tt.value, cb.value
 
-    def wsi_write(self) -> bytes:
-        """WriteMIC3 around the session's coded planes: the file CompressWSI returns"""
-        out = np.empty(self._wsi_bytes + 64, dtype=np.uint8); n = C.c_size_t(0)
-        rc = lib().mic_hip_session_wsi_write(self._h, out.ctypes.data, out.size, C.byref(n))
+    def wsi_write(self, out: Optional[np.ndarray] = None):
+        """WriteMIC3 around the session's coded planes: the file CompressWSI returns, as bytes -- or, with `out` (a uint8 array of
+        the caller's, ordinary or pinned), written there: returns its length"""
+        buf = out if out is not None else np.empty(self._wsi_bytes + 64, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = lib().mic_hip_session_wsi_write(self._h, buf.ctypes.data, buf.size, C.byref(n))
         if rc:
             _raise(rc, "session_wsi_write")
-        return out[: n.value].tobytes()
+        return n.value if out is not None else buf[: n.value].tobytes()
 
     def wsi_payload(self, total_tiles: int) -> Tuple[int, int, np.ndarray]:
         """-> (device address of the container's payload, its size, tile lengths in container order); valid until the next wsi call"""

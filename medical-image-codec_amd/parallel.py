@@ -332,12 +332,14 @@ def downsample2x(img):
 
 
 def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int = 256, tile_h: int = 256, levels_req: int = 0,
-                      channels: int = 3, bits: int = 8, group=None) -> Optional[bytes]:
+                      channels: int = 3, bits: int = 8, group=None, out: Optional[np.ndarray] = None):
     """CompressWSI over the ranks.  band: this rank's rows of the slide (wsi_band_plan's (y0, y1)) as a (rows, width[, channels])
     tensor on the backend's device; encode_slide(image tensor, levels) -> (payload: uint8 tensor on the backend's device holding
     every tile blob of that image in container order, tile sizes: int64 numpy array, level table [(w, h, tiles across, tiles
     down)]) -- the injected codec: a mic_hip session on a GPU (session_wsi_codec: the payload never leaves the device), the
-    oracle in the CPU tests (slide_codec_from_bytes).  Rank 0 returns the slide's MIC3 file, the others None."""
+    oracle in the CPU tests (slide_codec_from_bytes).  Rank 0 returns the slide's MIC3 file as bytes, the others None; with
+    `out` (a uint8 array of the caller's -- pinned memory makes the one device-to-host copy a plain DMA) rank 0 writes the file
+    there and returns its length."""
     import torch
     dist, world, rank = _dist(group)
     levels = wsi_levels(width, height, tile_w, tile_h, levels_req)
@@ -383,8 +385,15 @@ def dist_compress_wsi(encode_slide, band, width: int, height: int, tile_w: int =
         assert [tuple(a) for a in tlv] == [tuple(a) for a in levels[K + 1:]], (tlv, levels[K + 1:])
         pieces.append(tp); out_sizes.extend(np.asarray(tsz).tolist())
     assert len(out_sizes) == sum(a[2] * a[3] for a in levels)
-    body = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=dev)
-    return mic3_header(width, height, tile_w, tile_h, channels, bits, levels, out_sizes) + body.cpu().numpy().tobytes()
+    body = torch.cat(pieces) if len(pieces) != 1 else pieces[0]
+    hdr = mic3_header(width, height, tile_w, tile_h, channels, bits, levels, out_sizes)
+    if out is None:
+        return hdr + body.cpu().numpy().tobytes()
+    total = len(hdr) + body.numel()
+    assert out.dtype == np.uint8 and out.size >= total, "dist_compress_wsi: out is too small"
+    out[: len(hdr)] = np.frombuffer(hdr, dtype=np.uint8)
+    torch.from_numpy(out[len(hdr): total]).copy_(body)                       # one device-to-host copy, straight into the caller's buffer
+    return total
 
 
 def slide_codec_from_bytes(encode_file, device="cpu"):
