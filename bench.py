@@ -153,11 +153,13 @@ def unit_codec_leg(mic, torch, d_px, units, steps, warmup, what):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         offs, _ = step()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    el = float(np.mean(times))
     assert torch.equal(d_out, d_px), f"{what}: round trip differs"
     kmean = mean_timings([step(True)[1] for _ in range(2)])
     sess.close()
@@ -165,7 +167,8 @@ def unit_codec_leg(mic, torch, d_px, units, steps, warmup, what):
     comp = int(offs[-1])
     enc_ms = sum(v for k, v in kmean.items() if k.startswith("k_enc") or k.startswith("k_scan"))
     dec_ms = sum(v for k, v in kmean.items() if k.startswith("k_dec"))
-    return {"value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "ratio": round(raw / comp, 4),
+    return {"value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "steps": steps,
+            "ms_min": round(min(times) * 1e3, 3), "ms_median": round(float(np.median(times)) * 1e3, 3), "ratio": round(raw / comp, 4),
             "raw_bytes": raw, "units": n_units,
             "encode_GBps_kernels": round(raw / (enc_ms * 1e-3) / 1e9, 4) if enc_ms else None,
             "decode_GBps_kernels": round(raw / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
@@ -194,17 +197,20 @@ def leg_wavelet(mic, torch, synth, dev, steps, warmup, nframes=256):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         offs, _ = step()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    el = float(np.mean(times))
     assert torch.equal(d_out, d_px), "wavelet round trip differs"
     kmean = mean_timings([step(2)[1] for _ in range(2)])
     sess.close()
     raw, comp = d_px.numel() * 2, int(offs[-1]) + 11 * nframes
     return {"workload": f"WaveletV2 (5 levels) encode+decode, {nframes} CR-like {cols}x{rows} 12-bit synthetic frames per launch, device-resident",
-            "value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "ratio": round(raw / comp, 4), "raw_bytes": raw,
+            "value": round(raw / el / 1e9, 4), "unit": "GB/s", "ms_per_step": round(el * 1e3, 3), "steps": steps,
+            "ms_min": round(min(times) * 1e3, 3), "ms_median": round(float(np.median(times)) * 1e3, 3), "ratio": round(raw / comp, 4), "raw_bytes": raw,
             "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02}, "roofline": roofline_block(kmean, raw, comp)}
 
 
@@ -277,10 +283,12 @@ def leg_wsi(mic, torch, synth, dev, steps, size=32768):
     raw_l0 = size * size * 3
     tile_rgb_bytes = sum(((w + 255) // 256) * ((h + 255) // 256) for w, h in lv) * 256 * 256 * 3       # RGB bytes of every tile incl. padding, all levels
     el = float(np.mean(enc_t) + np.mean(dec_t))
+    tot_t = [a + b for a, b in zip(enc_t, dec_t)]
     # 3 N (1 + 1/r) with N = tile pixels including padding (all levels), r = that / compressed bytes
     return {"workload": f"MIC3 encode (pyramid + tiles + planes) and decode (every tile of every level), synthetic H&E-like {size}x{size} RGB slide, "
                         f"256x256 tiles, {len(lv)} levels, {tiles} tiles, device-resident",
             "value": round(raw_l0 / el / 1e9, 4), "unit": "GB/s (level-0 RGB bytes / encode+decode time)", "ms_per_step": round(el * 1e3, 3),
+            "steps": steps, "ms_min": round(min(tot_t) * 1e3, 3), "ms_median": round(float(np.median(tot_t)) * 1e3, 3),
             "encode_ms": round(float(np.mean(enc_t)) * 1e3, 3), "decode_ms": round(float(np.mean(dec_t)) * 1e3, 3),
             "ratio": round(raw_l0 / nbytes, 4), "raw_bytes": raw_l0, "compressed_bytes": nbytes,
             "container_assembly_ms": round(t_write * 1e3, 3), "container_assembly_pageable_ms": round(t_write_pageable * 1e3, 3),
@@ -531,7 +539,7 @@ def main():
         dom = max(kmean, key=kmean.get)
         traffic = None                                                    # HBM bytes of the dominant kernel from the committed PMC passes (same command)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
             ent = tj.get(dom)
             if ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
                 traffic = ent["hbm_bytes_per_launch"]
@@ -596,27 +604,34 @@ def main():
     if world == 1 and not args.no_legs:
         # B in {1, 64, 288, 512}: kernel time of one encode+decode per batch size (report B = 1 honestly)
         sweep = []
-        for b in (1, 64, 288, 512):
+        for b in (1, 4, 16, 64, 288, 512):
             if b > B:
                 dsw = synth.xr_like_batch_torch(b, cols=W, rows=H, depth=args.depth, seed0=seed0, noise=noise, device=dev)
             else:
                 dsw = d_px[:b].contiguous()
             us = [(i * W * H + y0 * W, W, y1 - y0, maxv, 2) for i in range(b) for (y0, y1) in bounds]
-            r, km, _ = unit_codec_leg(mic, torch, dsw, us, 2, 1, f"sweep B={b}")
-            sweep.append({"frames": b, "strips": len(us), "GBps": r["value"], "ms_per_step": r["ms_per_step"],
+            r, km, _ = unit_codec_leg(mic, torch, dsw, us, 10 if b <= 64 else 5, 1, f"sweep B={b}")
+            enc_k = sum(v for k, v in km.items() if k.startswith("k_enc") or k.startswith("k_scan"))
+            dec_k = sum(v for k, v in km.items() if k.startswith("k_dec"))
+            sweep.append({"frames": b, "strips": len(us), "GBps": r["value"], "ms_per_step": r["ms_per_step"], "ms_min": r["ms_min"], "ms_median": r["ms_median"],
+                          "encode_kernels_ms": round(enc_k, 3), "decode_kernels_ms": round(dec_k, 3),
                           "encode_GBps_kernels": r["encode_GBps_kernels"], "decode_GBps_kernels": r["decode_GBps_kernels"]})
             del dsw
         out["batch_sweep"] = sweep
+        # config 2 read literally ("encode+decode of XR_2577_2048_image.bin": ONE image) is eight serial entropy chains: say so up front
+        out["b1"] = {"encode_kernels_ms": sweep[0]["encode_kernels_ms"], "decode_kernels_ms": sweep[0]["decode_kernels_ms"],
+                     "ms_per_step": sweep[0]["ms_per_step"], "GBps": sweep[0]["GBps"],
+                     "note": "one frame = 8 strips = 8 serial tANS chains of ~330k rounds: latency, whatever the chip's width"}
         del d_out
         torch.cuda.empty_cache()
         legs = {}
-        legs["config3_wavelet_v2_cr"] = leg_wavelet(mic, torch, synth, dev, 3, 1)
+        legs["config3_wavelet_v2_cr"] = leg_wavelet(mic, torch, synth, dev, 10, 1)
         torch.cuda.empty_cache()
-        legs["config4_mic2_512cubed"] = leg_mic2(mic, torch, synth, dev, 3, 1)
+        legs["config4_mic2_512cubed"] = leg_mic2(mic, torch, synth, dev, 10, 2)
         torch.cuda.empty_cache()
         del d_px
         torch.cuda.empty_cache()
-        legs["config5_mic3_wsi_32768"] = leg_wsi(mic, torch, synth, dev, 2)
+        legs["config5_mic3_wsi_32768"] = leg_wsi(mic, torch, synth, dev, 10)
         out["legs"] = legs
         if "roofline" in out:
             out["roofline_fracs"] = {"config2_pics8_xr": out["roofline"]["frac"], **{k: (v["roofline"] or {}).get("frac") for k, v in legs.items()}}
@@ -634,6 +649,19 @@ def main():
             out["cpu_baseline"] = port
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and out.get("cpu_baseline") and out.get("batch_sweep"):
+        # smallest batch at which the device (frames resident in HBM) outruns this box's host cores on the same frames
+        cpu = out["cpu_baseline"]["value"]
+        sw = out["batch_sweep"]
+        cross = None
+        for a, b in zip(sw, sw[1:]):
+            if a["GBps"] < cpu <= b["GBps"]:
+                f = (cpu - a["GBps"]) / (b["GBps"] - a["GBps"])
+                cross = int(np.ceil(a["frames"] + f * (b["frames"] - a["frames"])))
+                break
+        if cross is None and sw[0]["GBps"] >= cpu:
+            cross = sw[0]["frames"]
+        out["crossover_frames"] = cross
     if dist is not None:
         dist.barrier()
     if rank == 0:
