@@ -4,7 +4,7 @@
 # usage: tools/profile_bench.sh <outdir-under-gpurun_out> [bench args]
 set -uo pipefail
 OUT=gpurun_out/${1:-prof}; shift || true
-ARGS="--no-cpu --no-legs --steps 3 --warmup 1 $*"
+ARGS="--no-cpu --no-legs --no-e2e --steps 3 --warmup 1 $*"
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
@@ -12,9 +12,9 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT \
     -d $OUT/sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
-python3 bench.py --no-cpu --no-legs > $OUT/bench_plain.json 2> $OUT/plain.err
+python3 bench.py --no-cpu --no-legs --no-e2e > $OUT/bench_plain.json 2> $OUT/plain.err
 # the other BASELINE configurations (bench.py's legs): kernel trace only
-rocprofv3 --kernel-trace --stats -d $OUT/legs -- python3 bench.py --no-cpu --legs-only > $OUT/bench_legs_trace.json 2> $OUT/legs.err
+rocprofv3 --kernel-trace --stats -d $OUT/legs -- python3 bench.py --no-cpu --no-e2e --legs-only > $OUT/bench_legs_trace.json 2> $OUT/legs.err
 LG=$(find $OUT/legs -name "*.db" | head -1)
 python3 - "$LG" $OUT/summary_legs_kernel_stats.csv <<'PY'
 import csv, sqlite3, sys
