@@ -114,9 +114,10 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
     int rc = s->ensure(n, max_px);
     if (rc) return rc;
     { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
-    bool any_grad = false;
+    bool any_grad = false, narrow = true;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
+        narrow &= (units[i].nstates & 0xFF) <= 2;
         u.px_in = d_pixels + units[i].px_offset;
         u.w = units[i].width; u.h = units[i].height;
         u.max_value = units[i].max_value; u.nstates = units[i].nstates & 0xFF;
@@ -128,7 +129,7 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(n))) return rc;
     s->timer.reset(s->stream);
-    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer);
+    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0) | (narrow ? MIC_VARIANT_NARROW : 0), &s->timer);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->n_last = n;
     return MIC_OK;

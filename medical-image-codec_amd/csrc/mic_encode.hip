@@ -709,7 +709,7 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 // otherwise every coding step gathers them from HBM.
 template <int N, bool RANS, bool TTL, int T>
 __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
-                          uint16_t (*s_E)[8], uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {
+                          uint16_t *s_E, uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {   // s_E: T x N end states
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
     const mic_gp<const uint16_t> src = mic_g((const uint16_t *)u.tok);
@@ -815,7 +815,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         rec_store(g, st, bits);
     }
 #pragma unroll
-    for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(st[k] - size);
+    for (int k = 0; k < N; k++) s_E[(tid) * N + k] = (uint16_t)(st[k] - size);
     MIC_STAMP_AT(u, 8);
     // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
     for (uint32_t round = 0; round < T; round++) {
@@ -824,8 +824,8 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         uint32_t e_out[N], st2[N]; bool any = false;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            e_out[k] = (uint32_t)s_E[tid][k] + size;
-            const uint32_t e_prev = (tid > 0) ? (uint32_t)s_E[tid - 1][k] + size : size;
+            e_out[k] = (uint32_t)s_E[(tid) * N + k] + size;
+            const uint32_t e_prev = (tid > 0) ? (uint32_t)s_E[(tid - 1) * N + k] + size : size;
             if (tid > 0 && e_prev != assumed[k]) { assumed[k] = e_prev; any = true; }
             st2[k] = e_prev;
         }
@@ -855,7 +855,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         }
         __syncthreads();                                   // every thread has read its predecessor's states
 #pragma unroll
-        for (int k = 0; k < N; k++) s_E[tid][k] = (uint16_t)(e_out[k] - size);
+        for (int k = 0; k < N; k++) s_E[(tid) * N + k] = (uint16_t)(e_out[k] - size);
 #ifdef MIC_STAMP
         if (tid == 0) u.dbg[12] += 1;                                     // rounds
 #endif
@@ -867,7 +867,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     if (tid == 0) {
         // last thread that owns tokens
         uint32_t last = (nblk + per - 1) / per; if (last > 0) last--;
-        for (int k = 0; k < N; k++) s_E[T - 1][k] = s_E[last][k];
+        for (int k = 0; k < N; k++) s_E[(T - 1) * N + k] = s_E[(last) * N + k];
     }
     __threadfence_block();
     __syncthreads();
@@ -934,7 +934,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         uint32_t stp[N];
         const uint32_t lastown = (nblk + per - 1) / per;   // threads 0 .. lastown-1 own tokens; s_E[T-1] was overwritten for the trailer
 #pragma unroll
-        for (int k = 0; k < N; k++) stp[k] = (tid > 0 && tid < lastown) ? (uint32_t)s_E[tid - 1][k] + size : size;
+        for (int k = 0; k < N; k++) stp[k] = (tid > 0 && tid < lastown) ? (uint32_t)s_E[(tid - 1) * N + k] + size : size;
         // Four tokens (<= 64 bits) are gathered branch-free before they meet the accumulator: the test "does a 64-bit unit fill up"
         // is a divergent branch that some lane takes at almost every token, so it is made once per four of them.
         for (uint32_t b = b_hi; b > b_lo; b--) {
@@ -980,7 +980,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         const uint64_t end = pos + (uint64_t)N * tl + 1;
         for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
         for (int k = N - 1; k >= 0; k--) {
-            const uint64_t v = (uint64_t)((uint32_t)s_E[T - 1][k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
+            const uint64_t v = (uint64_t)((uint32_t)s_E[(T - 1) * N + k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
             const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
             words[wi] |= (uint32_t)(v << sh);
             if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
@@ -1006,14 +1006,19 @@ __device__ __forceinline__ int te_small_class(const MicUnit &u) {
     if (u.ntok > TE_SMALL_NTOK || u.table_log > 13 || u.symbol_len > TE_SMALL_SYMS) return 0;
     return (u.table_log <= 12 && u.symbol_len <= 512u) ? 1 : 2;
 }
-template <int TLHI, int T, int TTS>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16 (dynamic LDS = 2 << TLHI); threads; LDS coding records
-__global__ void __launch_bounds__(T, 4) k_enc_tans_wg(MicUnit *units) {
+// Dynamic LDS: the state table (2 << TLHI bytes), TTS coding records of 8 bytes, T x e_states end states of 2 bytes.  e_states is the
+// widest flavour a unit of the launch may ask for (2 when the whole batch is two-state: the 512-thread instance then takes 50 KiB
+// and THREE groups share a CU -- the kernel waits on LDS round trips most of its time, SQ_WAIT_ANY 0.73 of its wave cycles --
+// at 80 VGPRs; 8 otherwise).
+template <int TLHI, int T, int TTS>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16; threads; LDS coding records
+__global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *units, int e_states) {
     constexpr uint32_t tl_lo = (TLHI <= 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_stab[];
-    __shared__ uint16_t s_E[T][8];
+    uint16_t *const s_E = s_stab + (1u << TLHI) + (TLHI <= 15 ? (uint32_t)TTS * 4u : 0u);
     __shared__ uint32_t s_scan[(T / 64) + 2];
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.nstates_used != 0) return;
+    if ((u.nstates == 108 ? 8 : (int)u.nstates) > e_states) { if (threadIdx.x == 0) u.status = MICD_ERR_INTERNAL; return; }   // (the launcher sizes the LDS for e_states)
     const uint32_t tl = u.table_log;
     if (tl < tl_lo || tl > tl_hi) return;
     if (TLHI <= 13 && te_small_class(u) != (T == 64 ? (TLHI == 12 ? 1 : 2) : 0)) return;   // (small units: the one-wave instances)
@@ -1137,20 +1142,22 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     mic_launch_enc_tables(d_units, n, stream);
     static MicPerDeviceOnce once;
     once.run([] {
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     });
+    const int es = (variant & MIC_VARIANT_NARROW) ? 2 : 8;                      // widest flavour in the batch -> end-state area
+    const unsigned eb = TE_THREADS * (unsigned)es * 2u, eb1 = 64u * (unsigned)es * 2u;
     if (t) t->mark("k_enc_tans_wg<13>");
-    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
     if (t) t->mark("k_enc_tans_wg<13, one wave>");
-    hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8, stream, d_units);
-    hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8 + eb1, stream, d_units, es);
+    hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8 + eb1, stream, d_units, es);
     if (t) t->mark("k_enc_tans_wg<other classes>");
-    hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8, stream, d_units);
-    hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8, stream, d_units);
-    hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), 2u << 16, stream, d_units);
+    hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 16) + eb, stream, d_units, es);
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_enc_hist_clean");

@@ -48,6 +48,7 @@ struct MicTimer {
 
 // variant: launch flags -- MIC_VARIANT_GRAD when some unit has pred = 1 (their tokeniser / predictor instantiations are only launched then)
 #define MIC_VARIANT_GRAD 0x1000
+#define MIC_VARIANT_NARROW 0x2000       // encode: no unit of the batch asks for more than two states (sizes k_enc_tans_wg's end-state area)
 void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
 // d_cls: per-session scratch of MIC_CLS_INTS(n) ints for the per-class unit lists of the lane-per-state tANS decoder (mic_decode_ls.hip)
 #define MIC_CLS_HEAD 32
