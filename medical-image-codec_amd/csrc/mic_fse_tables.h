@@ -262,10 +262,16 @@ __device__ inline uint32_t mic_rd_u32(const uint8_t *b, uint32_t len, int64_t of
 // norm_cap: entries available in norm[]; MICD_ERR_UNSUPPORTED when the alphabet is larger (the
 // caller then parses again into the full 65536-entry array).
 // PREZEROED: norm[] is all zero on entry, so zero-runs only move the symbol cursor.
+// dw / boff (optional): the same bytes as aligned dwords, b = (const uint8_t *)dw + boff, readable up to b + len + 8 -- an LDS
+// stage.  The bulk of the header is then read through a 64-bit register window (one LDS dword per 32 bits consumed instead of a
+// byte-wise u32 per field): far from the end of the buffer the reference's reader state is a function of the bit position alone
+// (off = P >> 3, bitCount = P & 7, bitStream = the bits from P on), so the window reader is the same machine; the last sixteen
+// bytes -- where the reference's refill rules differ, fsedecompressu16.go:100-160 -- are left to the byte-wise loop below, which
+// takes over from the canonical state.
 template <typename NormT, bool PREZEROED = false>
 __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *norm,
                                       uint32_t *symbol_len_out, uint32_t *tl_out, uint32_t *consumed,
-                                      uint32_t norm_cap) {
+                                      uint32_t norm_cap, const uint32_t *dw = nullptr, uint32_t boff = 0) {
     uint32_t charnum = 0;
     bool previous0 = false;
     int err = 0;
@@ -281,6 +287,66 @@ __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *nor
     int32_t threshold = (int32_t)(1u << nb_bits);
     int32_t got_total = 0;
     nb_bits++;
+    if (dw && iend >= 24) {
+        uint64_t P = 4;                                                   // bit position, relative to b
+        const uint64_t lim = ((uint64_t)iend - 16) * 8;                   // an iteration starts (and a zero-run skip lands) at P <= lim only
+        uint32_t wi = 0xFFFFFFFEu; uint64_t W = 0;                        // window: dwords wi, wi + 1 (none yet)
+        auto snap = [&](uint64_t p) -> uint32_t {
+            const uint64_t pa = p + 8ull * boff;
+            const uint32_t i = (uint32_t)(pa >> 5);
+            if (i != wi) {
+                if (i == wi + 1) W = (W >> 32) | ((uint64_t)dw[i + 1] << 32);
+                else W = (uint64_t)dw[i] | ((uint64_t)dw[i + 1] << 32);
+                wi = i;
+            }
+            return (uint32_t)(W >> ((uint32_t)pa & 31u));
+        };
+        while (remaining > 1 && P <= lim) {
+            const uint64_t P0 = P;
+            uint32_t bs = snap(P);
+            if (previous0) {
+                uint32_t n0 = charnum;
+                bool bail = false;
+                while ((bs & 0xFFFF) == 0xFFFF) {
+                    n0 += 24; P += 16;
+                    if (P > lim) { bail = true; break; }
+                    bs = snap(P);
+                    if (n0 > MIC_MAXSYM + 24) return MICD_ERR_CORRUPT;
+                }
+                if (bail) { P = P0; break; }                              // (this iteration again, byte-wise)
+                while ((bs & 3) == 3) { n0 += 3; bs >>= 2; P += 2; }
+                n0 += bs & 3; P += 2;
+                if (n0 > MIC_MAXSYM) return MICD_ERR_CORRUPT;
+                if (n0 > norm_cap) return MICD_ERR_UNSUPPORTED;
+                if (PREZEROED) charnum = max(charnum, n0);
+                else while (charnum < n0) { norm[charnum & 0xffff] = 0; charnum++; }
+                bs = snap(P);
+            }
+            const int32_t max = (2 * threshold - 1) - remaining;
+            int32_t count;
+            if (((int32_t)bs & (threshold - 1)) < max) { count = (int32_t)bs & (threshold - 1); P += nb_bits - 1; }
+            else {
+                count = (int32_t)bs & (2 * threshold - 1);
+                if (count >= threshold) count -= max;
+                P += nb_bits;
+            }
+            count--;
+            if (count < 0) { remaining += count; got_total -= count; }
+            else { remaining -= count; got_total += count; }
+            if (charnum > MIC_MAXSYM) return MICD_ERR_CORRUPT;
+            if (charnum >= norm_cap) return MICD_ERR_UNSUPPORTED;
+            norm[charnum & 0xffff] = (NormT)count;
+            charnum++;
+            previous0 = (count == 0);
+            while (remaining < threshold) {
+                nb_bits--; threshold >>= 1;
+                if (threshold == 0) break;
+            }
+        }
+        off = (int64_t)(P >> 3); bit_count = (uint32_t)P & 7u;            // the canonical state of the byte-wise reader
+        bit_stream = mic_rd_u32(b, len, off, &err) >> bit_count;
+        if (err) return MICD_ERR_CORRUPT;
+    }
     while (remaining > 1) {
         if (previous0) {
             uint32_t n0 = charnum;

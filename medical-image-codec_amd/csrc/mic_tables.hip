@@ -522,7 +522,7 @@ template <bool BIG>
 __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
     constexpr uint32_t DP_STAGE = BIG ? 40u * 1024u : 8u * 1024u;
     constexpr uint32_t DP_SYMS = BIG ? 65536u : 8192u;
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DP_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DP_STAGE + 16];
     MicUnit &u = units[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t len = u.comp_len;
@@ -562,9 +562,10 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
             }
             // Parse from the staged bytes when that is certain to be identical: the whole blob is staged, or the
             // header ends well inside the stage; otherwise from HBM.
-            if (len <= DP_STAGE) rc = mic_read_ncount<int32_t, true>(s_in + off, len - off, u.norm, &symbol_len, &tl, &used, DP_SYMS);
+            // (the window reader may look 8 bytes past the bytes it is given: the stage is DP_STAGE + 16 bytes long)
+            if (len <= DP_STAGE) rc = mic_read_ncount<int32_t, true>(s_in + off, len - off, u.norm, &symbol_len, &tl, &used, DP_SYMS, (const uint32_t *)s_in, off);
             else {
-                rc = mic_read_ncount<int32_t, true>(s_in + off, DP_STAGE - off, u.norm, &symbol_len, &tl, &used, DP_SYMS);
+                rc = mic_read_ncount<int32_t, true>(s_in + off, DP_STAGE - off, u.norm, &symbol_len, &tl, &used, DP_SYMS, (const uint32_t *)s_in, off);
                 if (!(rc == MICD_OK && used + 8 < DP_STAGE - off)) {
                     if (!BIG) rc = MICD_ERR_UNSUPPORTED;
                     else {
