@@ -890,6 +890,39 @@ def test_pics_files_decode_with_the_reference_c_decoder(mic, mico, synth, gpu_re
                 assert np.array_equal(back, img), (strips, ns, fn)
 
 
+def test_pics_and_mic2_payloads_are_reference_written_bytes_when_every_unit_holds_max_value(mic, synth, gpu_ready):
+    """PICS strips and MIC2 frames are CompressSingleFrame(unit, GLOBAL maxValue) (parallelstrips.go:88, multiframecompress.go:201);
+    the reference's C encoder derives maxValue from the unit it is given (ojph/mic_compress_c.c:774-775).  Where every unit holds a
+    pixel equal to the global maximum the two agree, and the container payloads -- not only their readers -- are pinned to bytes the
+    reference wrote: strip s of the PICS file == mic_compress_two_state(strip s), frame i of the MIC2 file likewise."""
+    import ctypes as C
+    L = _ref_codec()
+
+    def ref_two_state(px):
+        px = np.ascontiguousarray(px)
+        out = np.empty(px.size * 4 + 135168, dtype=np.uint8)
+        n = C.c_size_t(0)
+        assert L.mic_compress_two_state(px.ctypes.data, px.shape[1], px.shape[0], out.ctypes.data, out.size, C.byref(n)) == 0
+        return out[: n.value].tobytes()
+
+    img = synth.xr_like(cols=2577, rows=2048, depth=12, seed=51).copy()
+    img[np.arange(0, 2048, 256) + 100, 1000] = 4095                              # one pixel at the global maximum in each of the 8 strips
+    assert int(img.max()) == 4095
+    pics = mic.compress_parallel_strips(img, 2577, 2048, 4095, 8)
+    tab = np.frombuffer(pics, dtype="<u4", count=16, offset=20).reshape(8, 2)
+    for s_ in range(8):
+        a = 20 + 64 + int(tab[s_, 0])
+        assert pics[a: a + int(tab[s_, 1])] == ref_two_state(img[s_ * 256:(s_ + 1) * 256]), s_
+    stack = synth.ct_stack(frames=12, size=512, depth=12, seed=9).copy()
+    mx = int(stack.max())
+    stack[:, 7, 7] = mx                                                           # every frame holds the stack's maximum
+    mic2 = mic.compress_multi_frame(stack, 512, 512, mx)
+    ft = np.frombuffer(mic2, dtype="<u4", count=24, offset=20).reshape(12, 2)
+    for i in range(12):
+        a = 20 + 96 + int(ft[i, 0])
+        assert mic2[a: a + int(ft[i, 1])] == ref_two_state(stack[i]), i
+
+
 def test_sub_batch_loops(gpu_ready):
     """The container calls cut long unit lists into sub-batches under a workspace ceiling (24 GiB); with MIC_HIP_WS_BUDGET_MB=8 the same
     loops run on small inputs (tests/chunking_check.py, a child process: the ceiling is read once per process)."""
