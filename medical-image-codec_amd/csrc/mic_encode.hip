@@ -707,7 +707,7 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 // tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
 // TTL: the per-symbol records (symbolTT / rANS freq+bias) were copied to LDS (alphabets up to TE_TT_SYMS);
 // otherwise every coding step gathers them from HBM.
-template <int N, bool RANS, bool TTL, int T>
+template <int N, bool RANS, bool TTL, int T, bool FS>   // FS: the LDS state table holds whole states (they fit 16 bits up to tableLog 15)
 __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                           uint16_t *s_E, uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {   // s_E: T x N end states
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -742,7 +742,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         } else {
             const uint32_t nb = (state + r.x) >> 16;
             nb_out = nb;
-            return size + s_stab[(int32_t)(state >> nb) + (int32_t)r.y];
+            return (FS ? 0u : size) + s_stab[(int32_t)(state >> nb) + (int32_t)r.y];
         }
     };
     MIC_STAMP_BEGIN();
@@ -1026,7 +1026,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
     if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
-    if (u.nstates != 108) { const mic_gp<const uint32_t> gst = mic_g((const uint32_t *)u.state_tab); for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(gst[i] - size); }
+    if (u.nstates != 108) { const mic_gp<const uint32_t> gst = mic_g((const uint32_t *)u.state_tab); for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(gst[i] - (TLHI <= 15 ? 0u : size)); }
     uint2 *s_tt = (uint2 *)(s_stab + (1u << TLHI));                              // TTS coding records, 8 bytes each
     const bool ttl = TLHI <= 15 && u.symbol_len <= TTS;
     if (ttl) {
@@ -1045,17 +1045,17 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
             if (TLHI <= 15 && ttl) {
-                if (rans) te_encode<8, true, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, true, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             } else {
-                if (rans) te_encode<8, true, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 2) te_encode<2, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else te_encode<1, false, false, T>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                if (rans) te_encode<8, true, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 8) te_encode<8, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 4) te_encode<4, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (lanes == 2) te_encode<2, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else te_encode<1, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             }
         }
         __syncthreads();
