@@ -105,6 +105,7 @@ size_t workspace_budget() {
 // ---- encode -------------------------------------------------------------------------------
 int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
     if (n <= 0) return MIC_ERR_ARGS;
+    if (n > 65535) return MIC_ERR_UNSUPPORTED;                           // units are a launch's grid y in several kernels: callers sub-batch
     size_t max_px = 0;
     for (int i = 0; i < n; i++) {
         if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
@@ -168,6 +169,7 @@ int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uin
 int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *begins, const uint64_t *ends,
                                  const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
     if (n <= 0) return MIC_ERR_ARGS;
+    if (n > 65535) return MIC_ERR_UNSUPPORTED;
     size_t max_px = 0;
     for (int i = 0; i < n; i++) {
         if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;

@@ -192,7 +192,7 @@ int next_cut(const std::vector<U> &units, int i0, size_t target) {
     while (i1 < n) {
         const size_t px = (size_t)units[(size_t)i1].w * (size_t)units[(size_t)i1].h;
         const size_t mp = std::max(max_px, px);
-        if (i1 > i0 && (unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > budget || (size_t)(i1 - i0) >= target)) break;
+        if (i1 > i0 && (unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > budget || (size_t)(i1 - i0) >= target || i1 - i0 >= 65535)) break;
         max_px = mp; i1++;
     }
     return i1;

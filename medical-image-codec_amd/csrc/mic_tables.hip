@@ -554,6 +554,9 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
                 else if (s_in[1] == 0x04) flavour = 4;
                 else if (s_in[1] == 0x02) flavour = 2;
             }
+            // a WaveletV2 stream is decoded by FSEDecompressU16FourState and nothing else (waveletfsecompressu16.go:504): on the
+            // device-resident path nobody has looked at the magic bytes yet
+            if (u.walk_mode == 1 && flavour != 4) { rc = MICD_ERR_CORRUPT; break; }
             if (flavour != 1) {
                 if (len < 6) { rc = MICD_ERR_CORRUPT; break; }
                 count = (uint32_t)s_in[2] | ((uint32_t)s_in[3] << 8) | ((uint32_t)s_in[4] << 16) | ((uint32_t)s_in[5] << 24);

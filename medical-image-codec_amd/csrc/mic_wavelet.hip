@@ -783,6 +783,10 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
                          std::vector<int32_t> &st) {
     const size_t n = (size_t)rows * (size_t)cols;
     int rc;
+    // everything the launches below assume is checked before the first of them: grid limits, stream ranges
+    if (nf <= 0 || nf > 65535 || n >= ((size_t)65535 * WS_T)) return MIC_ERR_UNSUPPORTED;
+    for (int i = 0; i < nf; i++)
+        if (offs[(size_t)i + 1] < offs[(size_t)i] || offs[(size_t)i + 1] - offs[(size_t)i] > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
     if ((rc = s->ensure(nf, 2 * n + 16))) return rc;
     DevBuf &a = s->wv_a, &b = s->wv_b;
     if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
@@ -799,7 +803,6 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     mic_launch_decode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer, (int *)s->cls.p);
     const WvDims d = wv_dims(rows, cols, levels);
     if (s->timer.used) { s->timer.used--; s->timer.names.pop_back(); }   // (drop the chain's "end" mark: the wavelet kernels follow)
-    if (n >= ((size_t)65535 * WS_T) || nf > 65535) return done(MIC_ERR_UNSUPPORTED);
     s->timer.mark("k_rle_walk_parts+fix+compact");
     hipLaunchKernelGGL(k_rle_walk_parts, dim3(WP_PARTS, (unsigned)nf), dim3(64), 0, s->stream, (MicUnit *)s->units.p);
     hipLaunchKernelGGL(k_rle_walk_fix, dim3((unsigned)nf), dim3(64), 0, s->stream, (MicUnit *)s->units.p);
