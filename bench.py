@@ -580,6 +580,8 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02},
             "roofline": roofline_block(kmean, raw_bytes, comp_bytes, traffic),
             "container_assembly": assembly,
+            "workspace": {"session_bytes": sess.workspace_bytes()[0], "tier2": sess.workspace_bytes()[1],
+                          "x_input": round(sess.workspace_bytes()[0] / raw_bytes, 2)},
         }
     sess.close()
 

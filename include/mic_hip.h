@@ -309,6 +309,11 @@ int  mic_hip_session_create(mic_hip_session **s, int max_units, size_t max_px_pe
  * device current for the calling thread first, so one host process can own a session per GPU and drive them from any thread. */
 int  mic_hip_session_create_on(int device, mic_hip_session **s, int max_units, size_t max_px_per_unit);
 int  mic_hip_session_device(mic_hip_session *s);
+/* Device memory the session holds (bytes).  The unit codec lays its per-unit slabs out in two tiers: tier 1 -- one token per pixel
+ * and an eighth, tables for 8192 symbols: about 7 bytes per pixel + 0.2 MB per unit -- is where every batch starts; a batch in
+ * which a unit would cross a tier-1 capacity (more escapes than that, a 14-bit-and-up alphabet) is run again on the worst-case
+ * slabs (42 bytes per pixel + 1.7 MB) and the session stays there: *tier2 (may be NULL) says so.  Results never depend on the tier. */
+size_t mic_hip_session_workspace_bytes(mic_hip_session *s, int *tier2);
 void mic_hip_session_destroy(mic_hip_session *s);
 
 typedef struct mic_hip_unit {

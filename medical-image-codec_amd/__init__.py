@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -106,7 +107,7 @@ ABI_SYMBOLS = [
     "mic_hip_mic1_compress", "mic_hip_mic1_info", "mic_hip_mic1_decompress",
     "mic_hip_wsi_compress", "mic_hip_wsi_compress_ex", "mic_hip_wsi_format", "mic_hip_wsi_info", "mic_hip_wsi_level_info",
     "mic_hip_wsi_decompress_tile", "mic_hip_wsi_decompress_level", "mic_hip_wsi_decompress_region",
-    "mic_hip_session_create", "mic_hip_session_create_on", "mic_hip_session_device", "mic_hip_session_destroy", "mic_hip_session_stream",
+    "mic_hip_session_create", "mic_hip_session_create_on", "mic_hip_session_device", "mic_hip_session_workspace_bytes", "mic_hip_session_destroy", "mic_hip_session_stream",
     "mic_hip_device_copy",
     "mic_hip_session_wavelet_v2_encode", "mic_hip_session_wavelet_v2_decode",
     "mic_hip_session_wsi_encode", "mic_hip_session_wsi_write", "mic_hip_session_wsi_payload", "mic_hip_session_wsi_decode_level", "mic_hip_session_wsi_levels",
@@ -119,6 +120,28 @@ ABI_SYMBOLS = [
 _lib: Optional[C.CDLL] = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and ask for it by
+    the bare name, which the loader does not match against /opt/rocm's copy once libmic_hip.so has pulled that in: a process that
+    loads this library first and imports torch afterwards ends up with two runtimes, and the second one finds no GPU.  When a torch
+    install is present its copy is loaded first (by path, without importing torch), so either import order gives one runtime."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Loads libmic_hip.so (built in-tree by csrc/build.sh); fails loudly when missing."""
     global _lib
@@ -127,6 +150,7 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run medical-image-codec_amd/csrc/build.sh "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.mic_hip_device_name.restype = C.c_char_p
     L.mic_hip_version.restype = C.c_char_p
@@ -136,6 +160,8 @@ def lib() -> C.CDLL:
     L.mic_hip_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mic_hip_session_create_on.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]
     L.mic_hip_session_device.argtypes = [C.c_void_p]
+    L.mic_hip_session_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.mic_hip_session_workspace_bytes.restype = C.c_size_t
     L.mic_hip_session_wavelet_v2_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int)]
     L.mic_hip_session_wavelet_v2_decode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -844,6 +870,12 @@ class Session:
         if rc:
             _raise(rc, "session_wsi_write")
         return n.value if out is not None else buf[: n.value].tobytes()
+
+    def workspace_bytes(self) -> Tuple[int, bool]:
+        """(device bytes the session holds, whether a batch has needed the tier-2 slabs)"""
+        t = C.c_int(0)
+        n = lib().mic_hip_session_workspace_bytes(self._h, C.byref(t))
+        return int(n), bool(t.value)
 
     def wsi_payload(self, total_tiles: int) -> Tuple[int, int, np.ndarray]:
         """-> (device address of the container's payload, its size, tile lengths in container order); valid until the next wsi call"""

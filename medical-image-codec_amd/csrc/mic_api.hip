@@ -103,16 +103,13 @@ size_t workspace_budget() {
 }
 
 // ---- encode -------------------------------------------------------------------------------
-int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
-    if (n <= 0) return MIC_ERR_ARGS;
-    if (n > 65535) return MIC_ERR_UNSUPPORTED;                           // units are a launch's grid y in several kernels: callers sub-batch
+// A launch chain in the given tier.  Tier 1 (the small slabs) is where a batch starts unless the session has needed tier 2 before or
+// a unit's depth says so (14 bits and more: an alphabet past the 8192-bin tables); session_*_finish runs the batch again in tier 2
+// when a unit reports MICD_INT_GROW.
+static int encode_enqueue_tier(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n, int tier) {
     size_t max_px = 0;
-    for (int i = 0; i < n; i++) {
-        if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
-        max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
-    }
-    if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
-    int rc = s->ensure(n, max_px);
+    for (int i = 0; i < n; i++) max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
+    int rc = s->ensure(n, max_px, tier);
     if (rc) return rc;
     { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false, narrow = true;
@@ -124,8 +121,7 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
         u.max_value = units[i].max_value; u.nstates = units[i].nstates & 0xFF;
         u.pred = (units[i].nstates & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
         s->fill_workspace(u, i);
-        u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
-        if (!(u.nstates == 2 || u.nstates == 4 || u.nstates == 8) || (units[i].nstates & ~(0xFF | MIC_HIP_PRED_GRAD))) return MIC_ERR_ARGS;
+        u.tok_cap = (uint32_t)tok_cap_tier((size_t)u.w * (size_t)u.h, tier);
     }
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(n))) return rc;
@@ -136,11 +132,49 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
     return MIC_OK;
 }
 
+int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
+    if (n <= 0) return MIC_ERR_ARGS;
+    if (n > 65535) return MIC_ERR_UNSUPPORTED;                           // units are a launch's grid y in several kernels: callers sub-batch
+    size_t max_px = 0;
+    bool deep = false;
+    for (int i = 0; i < n; i++) {
+        if (units[i].width <= 0 || units[i].height <= 0) return MIC_ERR_ARGS;
+        max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
+        const int ns = units[i].nstates & 0xFF;
+        if (!(ns == 2 || ns == 4 || ns == 8) || (units[i].nstates & ~(0xFF | MIC_HIP_PRED_GRAD))) return MIC_ERR_ARGS;
+        deep |= units[i].max_value >= (1u << 13);                        // depth 14+: tokens reach past 8192
+    }
+    if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
+    const int tier = (s->force_big || deep) ? 2 : 1;
+    s->retry.kind = 0;
+    if (tier == 1) { s->retry.kind = 1; s->retry.d_in = d_pixels; s->retry.units.assign(units, units + n); }
+    return encode_enqueue_tier(s, d_pixels, units, n, tier);
+}
+
+// reads the units back; a tier-1 chain that reported MICD_INT_GROW somewhere is run again in tier 2 first
+static int finish_units(mic_hip_session *s, int n) {
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        bool grow = false;
+        for (int i = 0; i < n; i++) grow |= s->h_units[(size_t)i].status == MICD_INT_GROW;
+        if (!grow) return MIC_OK;
+        if (pass == 1 || s->retry.kind == 0) break;                      // (tier 2 never reports it; a caller that laid the units out itself has no retry)
+        s->force_big = true;
+        const mic_hip_session::Retry r = s->retry;                       // (the enqueue below rewrites it)
+        int rc;
+        if (r.kind == 1) rc = encode_enqueue_tier(s, (const uint16_t *)r.d_in, r.units.data(), n, 2);
+        else rc = session_decode_enqueue_spans(s, (const uint8_t *)r.d_in, r.begins.data(), r.ends.data(), r.units.data(), n, (uint16_t *)r.d_out);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n; i++) if (s->h_units[(size_t)i].status == MICD_INT_GROW) s->h_units[(size_t)i].status = MICD_ERR_INTERNAL;
+    return MIC_OK;
+}
+
 int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
     int n = s->n_last;
     if (n <= 0) return MIC_ERR_ARGS;
-    HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    { const int frc = finish_units(s, n); if (frc) return frc; }
     uint64_t total = 0;
     for (int i = 0; i < n; i++) {
         const MicUnit &u = s->h_units[(size_t)i];
@@ -176,20 +210,29 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
         max_px = std::max(max_px, (size_t)units[i].width * (size_t)units[i].height);
     }
     if (max_px > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
-    int rc = s->ensure(n, max_px);
+    for (int i = 0; i < n; i++) if (ends[i] < begins[i] || ends[i] - begins[i] > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
+    const int tier = s->force_big ? 2 : 1;                               // (a stream's alphabet is not known before its header is parsed)
+    if (tier == 1) {                                                     // what a second run in tier 2 needs (the arrays may be the caller's temporaries)
+        mic_hip_session::Retry r;
+        r.kind = 2; r.d_in = d_blobs; r.d_out = d_pixels_out; r.units.assign(units, units + n);
+        r.begins.assign(begins, begins + n); r.ends.assign(ends, ends + n);
+        s->retry = std::move(r);
+        begins = s->retry.begins.data(); ends = s->retry.ends.data(); units = s->retry.units.data();
+    } else if (s->retry.kind != 0 && begins != s->retry.begins.data()) s->retry.kind = 0;
+    int rc = s->ensure(n, max_px, tier);
     if (rc) return rc;
     { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false;
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
-        uint64_t len = ends[i] - begins[i];
-        if (ends[i] < begins[i] || len > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
+        const uint64_t len = ends[i] - begins[i];
         u.comp_in = d_blobs + begins[i]; u.comp_len = (uint32_t)len;
         u.px_out = d_pixels_out + units[i].px_offset;
         u.w = units[i].width; u.h = units[i].height;
         u.pred = (units[i].nstates & MIC_HIP_PRED_GRAD) ? 1u : 0u; any_grad |= u.pred != 0;
         s->fill_workspace(u, i);
-        u.tok_cap = (uint32_t)tok_cap_for((size_t)u.w * (size_t)u.h);
+        u.tok_cap = (uint32_t)tok_cap_tier((size_t)u.w * (size_t)u.h, tier);
+        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for((size_t)u.w * (size_t)u.h) + 64, 0xFFFFFFF0u);   // (a bound on the symbols a frame can use, not a slab size: the symbol slab is idle on this side)
     }
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
@@ -203,15 +246,28 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
 int session_decode_finish(mic_hip_session *s, int32_t *h_status) {
     int n = s->n_last;
     if (n <= 0) return MIC_ERR_ARGS;
-    HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    { const int frc = finish_units(s, n); if (frc) return frc; }
     for (int i = 0; i < n; i++) h_status[i] = s->h_units[(size_t)i].status;
     return MIC_OK;
 }
 
 // (the host-pointer batch and container entry points live in mic_host_io.hip)
 
-size_t unit_ws_bytes(size_t px) { return tok_cap_for(px) * 4 + blob_cap_for(px) + (2 * px + 8) * 8 + px / 8 + kSym * 4 * 6 + kSym * 2 + 8192; }
+size_t unit_ws_bytes_tier(size_t px, int tier) {
+    const size_t tokc = tok_cap_tier(px, tier), ts = tab_syms_tier(tier);
+    return tokc * 4 + blob_cap_tok(tokc) + seg_cap_tier(px, tier) * 8 + px / 8 + ts * 4 * 6 + ts * 2 + 8192;
+}
+size_t unit_ws_bytes(size_t px) { return unit_ws_bytes_tier(px, 2); }      // (the paths that lay their units out themselves: tier 2)
+// Units of px pixels (x `mult` slabs each) a sub-batch of the tiered unit codec may hold: tier-1 slabs under the workspace ceiling --
+// and tier-2 slabs, should the batch have to run again, inside nine tenths of what the device can give this session.
+size_t batch_units_for(size_t px, size_t mult) {
+    const size_t n1 = workspace_budget() / (mult * unit_ws_bytes_tier(px, 1));
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = (size_t)32 << 30; }
+    const size_t held = tl_default ? tl_default->reserved_bytes() : 0;
+    const size_t n2 = (size_t)((double)(fr + held) * 0.9) / (mult * unit_ws_bytes_tier(px, 2));
+    return std::max<size_t>(1, std::min(n1, n2));
+}
 
 void put_u32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -415,7 +471,7 @@ int mic_hip_session_create_on(int device, mic_hip_session **out, int max_units, 
     mic_hip_session *s = new mic_hip_session();
     s->device = device;
     if ((rc = s->activate())) { delete s; return rc; }
-    rc = s->ensure(max_units, max_px_per_unit);
+    rc = s->ensure(max_units, max_px_per_unit, 1);                      // tier-1 slabs; a batch that needs the big ones grows them
     if (rc) { s->release(); delete s; return rc; }
     *out = s;
     return MIC_OK;
@@ -426,6 +482,12 @@ int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_p
     return mic_hip_session_create_on(dev, out, max_units, max_px_per_unit);
 }
 int mic_hip_session_device(mic_hip_session *s) { return s ? s->device : -1; }
+// device memory the session holds right now (workspace slabs, staging, stores), and whether a batch has needed the tier-2 slabs
+size_t mic_hip_session_workspace_bytes(mic_hip_session *s, int *tier2) {
+    if (!s) return 0;
+    if (tier2) *tier2 = s->force_big ? 1 : 0;
+    return s->reserved_bytes();
+}
 void mic_hip_session_destroy(mic_hip_session *s) { if (s) { (void)s->activate(); s->release(); delete s; } }
 void *mic_hip_session_stream(mic_hip_session *s) { return s ? (void *)s->stream : nullptr; }
 

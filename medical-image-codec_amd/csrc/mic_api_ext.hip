@@ -210,7 +210,7 @@ int decode_blobs(const Mic3 &m, const std::vector<TileBlob> &tiles, const std::v
     const size_t ntile = tiles.size();
     const size_t P = (size_t)m.planes(), bpp = m.bpp();
     // per-tile chunking keeps the unit workspace bounded
-    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, kWorkspaceBudget / (P * unit_ws_bytes(npx))));   // (tiles are a launch's grid y)
+    const size_t per = std::min<size_t>(kMaxGridY / P, batch_units_for(npx, P));   // (tiles are a launch's grid y)
     struct Bufs { DevBuf planes, d_place, d_out; ~Bufs() { planes.release(); d_place.release(); d_out.release(); } } bufs;   // freed on every return path
     DevBuf &planes = bufs.planes, &d_place = bufs.d_place, &d_out = bufs.d_out;
     int rc;
@@ -302,7 +302,7 @@ int compress_level_tiles(mic_hip_session *s, const void *d_img, const Level &L, 
                          std::vector<uint8_t> *blobs_out) {
     const size_t P = (size_t)fmt.planes();
     const size_t npx = (size_t)tile_w * tile_h;
-    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)8 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(batch_units_for(npx, P), ((size_t)8 << 30) / (P * npx * 2))));
     DevBuf planes, stats;
     int rc = MIC_OK;
     const size_t ntl = (size_t)L.tx * L.ty;
@@ -694,7 +694,7 @@ namespace {
 int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_img, const Level &L) {
     const Mic3 &fmt = W.fmt;
     const size_t P = (size_t)fmt.planes(), npx = (size_t)fmt.tw * fmt.th;
-    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(batch_units_for(npx, P), ((size_t)16 << 30) / (P * npx * 2))));
     DevBuf &planes = s->wsi_planes, &stats = s->wsi_stats;
     const size_t ntl = (size_t)L.tx * L.ty;
     int rc;
@@ -937,7 +937,7 @@ int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_p
     const size_t P = (size_t)m.planes(), bpp = m.bpp(), npx = (size_t)m.tw * m.th;
     if ((size_t)L.w * L.h * bpp > out_cap) return MIC_ERR_CAPACITY;
     const size_t ntl = (size_t)L.tx * L.ty;
-    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(kWorkspaceBudget / (P * unit_ws_bytes(npx)), ((size_t)16 << 30) / (P * npx * 2))));
+    const size_t per = std::min<size_t>(kMaxGridY / P, std::max<size_t>(1, std::min<size_t>(batch_units_for(npx, P), ((size_t)16 << 30) / (P * npx * 2))));
     DevBuf &planes = s->wsi_planes, &aux = s->wsi_stats;
     for (size_t t0 = 0; t0 < ntl; t0 += per) {
         const size_t nt = std::min(per, ntl - t0);

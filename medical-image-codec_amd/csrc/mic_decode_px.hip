@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
             uint32_t j = 0;
             while (j < 64 && pos + j < ntok && outp < symcap) {
                 uint32_t h = __builtin_amdgcn_readlane(w, (int)j);
-                if (nseg >= segcap) { err = 1; break; }
+                if (nseg >= segcap) { err = 2; break; }               // (2: the segment slab is full -- tier 1: the batch runs again in tier 2)
                 // No encoder writes a count of 0, but the reference decodes one (DecodeNext2 keeps the count in a uint16: 0 passes as a run,
                 // is decremented to 65535 and counts down from there as a literal chunk): one symbol = the token behind the header, then the
                 // 65535 - midCount tokens behind that -- a literal chunk of 65536 - midCount symbols whose payload starts behind the header.
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units)
     }
     __syncthreads();
     const uint32_t nseg = s_misc[0], nsym = s_misc[1];
-    if (s_misc[2]) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }
+    if (s_misc[2]) { if (tid == 0) u.status = (s_misc[2] == 2 && u.tier == 1) ? MICD_INT_GROW : MICD_ERR_CORRUPT; return; }
 
     // ---- phases 2+3, tile by tile: expansion, escape markers, pixel numbering ------------------------
     if (nsym < 1 || nseg < 1) { if (tid == 0) u.status = MICD_ERR_CORRUPT; return; }

@@ -22,6 +22,7 @@
 #define MICD_ERR_INTERNAL       -8
 #define MICD_ERR_UNSUPPORTED    -9
 #define MICD_ERR_INCOMPRESSIBLE -10
+#define MICD_INT_GROW           -21    // internal: a tier-1 slab would overflow; the host runs the batch again in tier 2 (never surfaces)
 
 struct MicUnit {
     // ---- inputs ------------------------------------------------------------------
@@ -36,6 +37,8 @@ struct MicUnit {
     uint32_t        no_fallback; // 1 = FSECompressU16* semantics (no N -> ... -> 1 chain)
     uint32_t        req_tl;   // ScratchU16.TableLog of a bare FSE call (fseu16.go:101-102); 0 = the default 11
     uint32_t        pred;     // mode 0: 0 = avg(left, top) predictor, 1 = gradient-adaptive (deltagradrlecompressu16.go)
+    uint32_t        tier;     // 1: the slabs below are the small ones -- crossing one of their capacities is MICD_INT_GROW, not an error
+    uint32_t        tab_cap;  // entries of hist / norm / tt_* / state_tab / tab_sym (8192 or 65536)
     // ---- per-unit workspace (HBM) ------------------------------------------------
     uint16_t *tok;            // RLE token stream (encode: produced, decode: FSE output)
     uint32_t  tok_cap;

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     const uint32_t thr2 = thr | (thr << 16), lim2 = (2 * thr - 2) | ((2 * thr - 2) << 16);
     const uint32_t hlo = (!SRC && delim >= TK_HWIN && thr > TK_HWIN / 2) ? thr - TK_HWIN / 2 : 0u;   // window [hlo, hlo + TK_HWIN)
     const mic_gp<uint32_t> ghist = mic_g(u.hist);
+    const uint32_t tabcap = u.tab_cap;
     for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) s_hist[i] = 0;
     for (uint32_t i = tid; i < 2 * (TK_WIN + 16); i += TK_THREADS) (&xs2[0][0])[i] = 0;
     if (tid < 16) { s_cnt[tid] = 0; s_run[tid] = 0; s_str[tid] = 0; s_tc[tid] = 0; }
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     auto count_tok = [&](uint32_t v) {
         const uint32_t d = v - hlo;
         if (d < TK_HWIN) atomicAdd(&s_hist[d], 1u);
-        else { (void)__hip_atomic_fetch_add(&ghist[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tmax = max(tmax, v); }
+        else if (v < tabcap) { (void)__hip_atomic_fetch_add(&ghist[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tmax = max(tmax, v); }
+        else s_ovf = 1;                                         // (tier 1: the histogram slab has 8192 bins)
     };
     if (tid == 0) {
         if (SRC) {
@@ -543,15 +545,18 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     }
     __syncthreads();
     // window counts land on top of whatever the HBM atomics put there (nothing: disjoint bins)
-    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) { const uint32_t vv = s_hist[i]; if (vv) (void)__hip_atomic_fetch_add(&ghist[hlo + i], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    for (uint32_t i = tid; i < TK_HWIN; i += TK_THREADS) {
+        const uint32_t vv = s_hist[i];
+        if (vv) { if (hlo + i < tabcap) (void)__hip_atomic_fetch_add(&ghist[hlo + i], vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else s_ovf = 1; }
+    }
     // what k_enc_tables_wg has to scan of the 65536 bins: the window and whatever was counted outside it
     tmax = tk_wave_incl_max(tmax, lane);
     if (lane == 63 && tmax) atomicMax(&s_tmaxall, tmax);
     __syncthreads();
     if (tid == 0) {
-        if (s_ovf || outp > cap) u.status = MICD_ERR_CAPACITY;
+        if (s_ovf || outp > cap) u.status = u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CAPACITY;
         else u.ntok = outp;
-        u.hist_hi = min(65536u, max(hlo + (uint32_t)TK_HWIN, s_tmaxall + 1u));
+        u.hist_hi = min(min(65536u, tabcap), max(hlo + (uint32_t)TK_HWIN, s_tmaxall + 1u));
     }
 }
 
@@ -563,10 +568,12 @@ __global__ void __launch_bounds__(256) k_enc_symbols(MicUnit *units) {
     MicUnit &u = units[blockIdx.y];
     if (u.mode != 1) return;
     const uint32_t n = (uint32_t)u.w;
+    // (a caller's symbols may be anything up to 65535: bare FSE units run on tier-2 slabs only -- every caller lays them out so)
+    const bool fits = n <= u.tok_cap && u.tier != 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        u.status = (n <= u.tok_cap) ? MICD_OK : MICD_ERR_CAPACITY; u.ntok = (n <= u.tok_cap) ? n : 0; u.blob_len = 0; u.nstates_used = 0;
+        u.status = fits ? MICD_OK : (u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CAPACITY); u.ntok = fits ? n : 0; u.blob_len = 0; u.nstates_used = 0;
     }
-    if (n > u.tok_cap) return;
+    if (!fits) return;
     const uint16_t *src = u.px_in; uint16_t *tok = u.tok; uint32_t *hist = u.hist;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint16_t v = src[i];
@@ -634,7 +641,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
             }
             for (int k = lanes - 1; k >= 0; k--) bw.add(st[k], tl);     // final states, last lane first
             bw.close();
-            if (bw.overflow) rc = MICD_ERR_CAPACITY;
+            if (bw.overflow) rc = u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CAPACITY;
             else if ((uint64_t)u.hdr_len + bw.len >= (uint64_t)n * 2) rc = MICD_ERR_INCOMPRESSIBLE; // fse2state.go:58-60
             else out_len = pos + u.hdr_len + bw.len;
         }
@@ -651,7 +658,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
         }
         u.status = rc;                                                  // error of the last attempt
         if (lanes == 1 || u.no_fallback) return;
-        if (rc == MICD_ERR_CAPACITY) return;
+        if (rc == MICD_ERR_CAPACITY || rc == MICD_INT_GROW) return;
         u.status = MICD_OK;                                             // try the next flavour
     }
 }
@@ -1025,7 +1032,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
     const uint32_t tid = threadIdx.x;
     const uint32_t n = u.ntok;
     const uint32_t size = 1u << tl;
-    if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = MICD_ERR_CAPACITY; return; }
+    if (u.sym_cap < ((n + TE_BLK - 1) / TE_BLK) * TE_BLK) { if (tid == 0) u.status = u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CAPACITY; return; }
     if (u.nstates != 108) { const mic_gp<const uint32_t> gst = mic_g((const uint32_t *)u.state_tab); for (uint32_t i = tid; i < size; i += T) s_stab[i] = (uint16_t)(gst[i] - (TLHI <= 15 ? 0u : size)); }
     uint2 *s_tt = (uint2 *)(s_stab + (1u << TLHI));                              // TTS coding records, 8 bytes each
     const bool ttl = TLHI <= 15 && u.symbol_len <= TTS;
@@ -1074,7 +1081,8 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
             return;
         }
         if (tid == 0) { u.count = (uint32_t)rc; u.bits_off = total_bytes; u.flavour = lanes; }   // probe: why the attempt failed
-        if (lanes == 1 || rc == MICD_ERR_CAPACITY || single) { if (tid == 0) u.status = rc; return; }
+        if (rc == MICD_ERR_CAPACITY && u.tier == 1) rc = MICD_INT_GROW;               // (the staging blob is tier 1's)
+        if (lanes == 1 || rc == MICD_ERR_CAPACITY || rc == MICD_INT_GROW || single) { if (tid == 0) u.status = rc; return; }
         __syncthreads();
     }
 }
@@ -1123,8 +1131,8 @@ __global__ void __launch_bounds__(1024) k_scan_lens(const MicUnit *units, int n,
 // in front of every one: 17 GB for a 32768^2 slide's 65 535 planes): everything below the tokeniser's bound, or all of it.
 __global__ void __launch_bounds__(256) k_enc_hist_clean(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
-    const uint32_t hi = (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u;
-    uint4 *h = (uint4 *)u.hist;                                           // (256 KiB-aligned slab)
+    const uint32_t hi = min(u.tab_cap, (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u);
+    uint4 *h = (uint4 *)u.hist;                                           // (a slab is a multiple of 32 KiB)
     for (uint32_t i = threadIdx.x; i < (hi + 3) / 4; i += 256) h[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 

@@ -187,12 +187,12 @@ struct DecUnit {
 template <class U>
 int next_cut(const std::vector<U> &units, int i0, size_t target) {
     const int n = (int)units.size();
-    size_t max_px = 0; int i1 = i0;
-    const size_t budget = workspace_budget();
+    size_t max_px = 0, cap = 0; int i1 = i0;
     while (i1 < n) {
         const size_t px = (size_t)units[(size_t)i1].w * (size_t)units[(size_t)i1].h;
         const size_t mp = std::max(max_px, px);
-        if (i1 > i0 && (unit_ws_bytes(mp) * (size_t)(i1 - i0 + 1) > budget || (size_t)(i1 - i0) >= target || i1 - i0 >= 65535)) break;
+        if (mp != max_px || cap == 0) cap = batch_units_for(mp, 1);
+        if (i1 > i0 && ((size_t)(i1 - i0 + 1) > cap || (size_t)(i1 - i0) >= target || i1 - i0 >= 65535)) break;
         max_px = mp; i1++;
     }
     return i1;

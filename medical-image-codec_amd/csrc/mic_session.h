@@ -82,8 +82,17 @@ struct PinnedUnits {
 
 constexpr size_t kSym = 65536;
 
-inline size_t tok_cap_for(size_t px) { return 4 * px + 16; }
-inline size_t blob_cap_for(size_t px) { return 8 + 131080 + 2 * tok_cap_for(px) + 16; }
+// Two tiers of per-unit slabs.  Tier 2 is the worst case: two tokens per pixel (every pixel an escape), a 65536-symbol alphabet,
+// a segment per token pair -- 42 bytes per pixel + 1.66 MB of tables.  Tier 1 is what well-formed data needs: one token per
+// pixel and an eighth, tables for 8192 symbols / tableLog 13, a segment per eight pixels -- 7 bytes per pixel + 0.2 MB.  The unit
+// codec runs in tier 1 first; a kernel that would cross a tier-1 capacity marks its unit MICD_INT_GROW and the batch is run
+// again in tier 2 (session_*_finish), so results never depend on the tier.
+inline size_t tok_cap_for(size_t px) { return 4 * px + 16; }                                  // tier 2 (and the legit bound of a stream's token count)
+inline size_t tok_cap_tier(size_t px, int tier) { return tier == 1 ? px + px / 8 + 4096 : tok_cap_for(px); }
+inline size_t blob_cap_tok(size_t tokc) { return 8 + 131080 + 2 * tokc + 16; }
+inline size_t blob_cap_for(size_t px) { return blob_cap_tok(tok_cap_for(px)); }
+inline size_t seg_cap_tier(size_t px, int tier) { return tier == 1 ? px / 8 + 1024 : 2 * px + 8; }
+inline size_t tab_syms_tier(int tier) { return tier == 1 ? 8192 : 65536; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace micapi
@@ -95,6 +104,10 @@ void mic_wsi_store_free(mic_hip_wsi_store *w);
 struct mic_hip_session {
     int device = 0;                         // the HIP device this session's stream and workspace live on (mic_hip_session_create_on)
     int max_units = 0; size_t max_px = 0;   // shape of the current workspace layout (see ensure)
+    int tier = 2;                           // tier of the current layout
+    bool force_big = false;                 // a batch of this session needed tier 2: later ones start there (sticky)
+    // what a tier-1 launch chain needs to be run again in tier 2 (session_*_finish)
+    struct Retry { int kind = 0; const void *d_in = nullptr; void *d_out = nullptr; std::vector<mic_hip_unit> units; std::vector<uint64_t> begins, ends; } retry;
     hipStream_t stream = nullptr;
     // Entry points may be called from any OS thread (cgo: any goroutine's thread), and a process may hold sessions on several
     // devices: every public call makes the session's device the calling thread's current one first.
@@ -117,7 +130,7 @@ struct mic_hip_session {
     int prepare_hist(int n) {
         if (hist.gen != hist_zero_gen) { hist_zero_gen = hist.gen; hist_zero_units = 0; }
         if ((size_t)n > hist_zero_units) {
-            HIP_TRY(hipMemsetAsync((char *)hist.p + kSym * 4 * hist_zero_units, 0, kSym * 4 * ((size_t)n - hist_zero_units), stream));
+            HIP_TRY(hipMemsetAsync((char *)hist.p + tab_syms * 4 * hist_zero_units, 0, tab_syms * 4 * ((size_t)n - hist_zero_units), stream));
             hist_zero_units = (size_t)n;
         }
         return MIC_OK;
@@ -127,53 +140,58 @@ struct mic_hip_session {
     std::vector<std::string> t_names; std::vector<float> t_ms;
     size_t tok_stride = 0, blob_stride = 0, seg_stride = 0, sym_stride = 0, flag_stride = 0;
 
-    int ensure(int n, size_t px) {
+    size_t tab_syms = kSym;                  // symbols / states the table slabs of the current layout hold per unit
+    int ensure(int n, size_t px, int want_tier = 2) {
         if (!stream) HIP_TRY(hipStreamCreate(&stream));
-        // The workspace takes the shape of the current call (n units of up to px pixels); buffers only ever grow.  Sizing
-        // for max(n) x max(px) over a session's history would ask for the bounding box of unrelated calls (one 4-megapixel
-        // wavelet frame, then 3000 WSI planes of 256 x 256).
-        if (n == max_units && px == max_px) return MIC_OK;
+        // The workspace takes the shape of the current call (n units of up to px pixels, in the tier asked for); buffers only ever
+        // grow.  Sizing for max(n) x max(px) over a session's history would ask for the bounding box of unrelated calls (one
+        // 4-megapixel wavelet frame, then 3000 WSI planes of 256 x 256).
+        if (n == max_units && px == max_px && want_tier == tier) return MIC_OK;
         int nn = n; size_t pp = px;
-        tok_stride = align_up(tok_cap_for(pp) * 2, 256);
-        blob_stride = align_up(blob_cap_for(pp), 256);
-        seg_stride = align_up((2 * pp + 8) * 8, 256);
-        sym_stride = align_up((tok_cap_for(pp) + 64) * 2, 256);   // + a block: the tANS encoder rounds its per-token states up to 32
+        const size_t tokc = tok_cap_tier(pp, want_tier), ts = tab_syms_tier(want_tier);
+        tok_stride = align_up(tokc * 2, 256);
+        blob_stride = align_up(blob_cap_tok(tokc), 256);
+        seg_stride = align_up(seg_cap_tier(pp, want_tier) * 8, 256);
+        sym_stride = align_up((tokc + 64) * 2, 256);       // + a block: the tANS encoder rounds its per-token states up to 32
         flag_stride = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
         int rc;
         if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
         if ((rc = cls.reserve(4 * MIC_CLS_INTS(nn)))) return rc;
         if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
-        if ((rc = hist.reserve(kSym * 4 * (size_t)nn))) return rc;
-        if ((rc = norm.reserve(kSym * 4 * (size_t)nn))) return rc;
-        if ((rc = tt_nb.reserve(kSym * 4 * (size_t)nn))) return rc;
-        if ((rc = tt_find.reserve(kSym * 4 * (size_t)nn))) return rc;
-        if ((rc = state_tab.reserve(kSym * 4 * (size_t)nn))) return rc;
-        if ((rc = tab_sym.reserve(kSym * 2 * (size_t)nn))) return rc;
-        if ((rc = cumul.reserve((kSym + 64) * 4 * (size_t)nn))) return rc;
+        if ((rc = hist.reserve(ts * 4 * (size_t)nn))) return rc;
+        if ((rc = norm.reserve(ts * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_nb.reserve(ts * 4 * (size_t)nn))) return rc;
+        if ((rc = tt_find.reserve(ts * 4 * (size_t)nn))) return rc;
+        if ((rc = state_tab.reserve(ts * 4 * (size_t)nn))) return rc;
+        if ((rc = tab_sym.reserve(ts * 2 * (size_t)nn))) return rc;
+        if ((rc = cumul.reserve((ts + 64) * 4 * (size_t)nn))) return rc;
         if ((rc = blob.reserve(blob_stride * (size_t)nn))) return rc;
         if ((rc = offsets.reserve(8 * ((size_t)nn + 1)))) return rc;
         if ((rc = seg.reserve(seg_stride * (size_t)nn))) return rc;
         if ((rc = sym.reserve(sym_stride * (size_t)nn))) return rc;
         if ((rc = flags.reserve(flag_stride * (size_t)nn))) return rc;
-        max_units = nn; max_px = pp;
+        if (ts != tab_syms) hist_unknown();                // (the histogram slabs are laid out anew: nothing is known to be zero)
+        max_units = nn; max_px = pp; tier = want_tier; tab_syms = ts;
         return MIC_OK;
     }
     void fill_workspace(MicUnit &u, int i) {
+        const size_t ts = tab_syms;
+        u.tier = (uint32_t)tier; u.tab_cap = (uint32_t)ts;
         u.tok = (uint16_t *)((char *)tok.p + tok_stride * (size_t)i);
-        u.tok_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px), 0xFFFFFFF0u);
-        u.hist = (uint32_t *)hist.p + kSym * (size_t)i;
-        u.norm = (int32_t *)norm.p + kSym * (size_t)i;
-        u.tt_nb = (uint32_t *)tt_nb.p + kSym * (size_t)i;
-        u.tt_find = (int32_t *)tt_find.p + kSym * (size_t)i;
-        u.state_tab = (uint32_t *)state_tab.p + kSym * (size_t)i;
-        u.tab_sym = (uint16_t *)tab_sym.p + kSym * (size_t)i;
-        u.cumul = (int32_t *)cumul.p + (kSym + 64) * (size_t)i;
+        u.tok_cap = (uint32_t)std::min<size_t>(tok_cap_tier(max_px, tier), 0xFFFFFFF0u);
+        u.hist = (uint32_t *)hist.p + ts * (size_t)i;
+        u.norm = (int32_t *)norm.p + ts * (size_t)i;
+        u.tt_nb = (uint32_t *)tt_nb.p + ts * (size_t)i;
+        u.tt_find = (int32_t *)tt_find.p + ts * (size_t)i;
+        u.state_tab = (uint32_t *)state_tab.p + ts * (size_t)i;
+        u.tab_sym = (uint16_t *)tab_sym.p + ts * (size_t)i;
+        u.cumul = (int32_t *)cumul.p + (ts + 64) * (size_t)i;
         u.blob = (uint8_t *)blob.p + blob_stride * (size_t)i;
-        u.blob_cap = (uint32_t)std::min<size_t>(blob_cap_for(max_px), 0xFFFFFFF0u);
+        u.blob_cap = (uint32_t)std::min<size_t>(blob_cap_tok(tok_cap_tier(max_px, tier)), 0xFFFFFFF0u);
         u.seg = (uint2 *)((char *)seg.p + seg_stride * (size_t)i);
-        u.seg_cap = (uint32_t)std::min<size_t>(2 * max_px + 8, 0xFFFFFFF0u);
+        u.seg_cap = (uint32_t)std::min<size_t>(seg_cap_tier(max_px, tier), 0xFFFFFFF0u);
         u.sym = (uint16_t *)((char *)sym.p + sym_stride * (size_t)i);
-        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_for(max_px) + 64, 0xFFFFFFF0u);
+        u.sym_cap = (uint32_t)std::min<size_t>(tok_cap_tier(max_px, tier) + 64, 0xFFFFFFF0u);
         u.flags = (uint32_t *)((char *)flags.p + flag_stride * (size_t)i);
     }
     size_t reserved_bytes() const {
@@ -216,6 +234,8 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_base, cons
                                  const mic_hip_unit *units, int n, uint16_t *d_pixels_out);
 int session_decode_finish(mic_hip_session *s, int32_t *h_status);
 size_t unit_ws_bytes(size_t px);
+size_t unit_ws_bytes_tier(size_t px, int tier);
+size_t batch_units_for(size_t px, size_t mult);   // units per sub-batch of the tiered unit codec (mic_api.hip)
 // MIC2 temporal pipeline (mic_temporal.hip)
 int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
                            uint8_t *out, size_t out_cap, size_t *out_len);

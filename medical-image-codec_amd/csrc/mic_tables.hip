@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
     uint32_t *s_tmp = (uint32_t *)(s_raw + TB_OFF_TMP);
     // ---- histogram scan: symbolLen and maxCount (fsecompressu16.go:438-462) -------------------------
     uint32_t m = 0, sl = 0;
-    const uint32_t hist_hi = (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u;   // (the tokeniser's bound on what it counted)
+    const uint32_t hist_hi = min(u.tab_cap, (u.hist_hi >= 1 && u.hist_hi <= MIC_MAXSYM) ? u.hist_hi : MIC_MAXSYM + 1u);   // (the tokeniser's bound on what it counted)
     for (uint32_t i = tid; i < hist_hi; i += TP_THREADS) {
         const uint32_t c = u.hist[i];
         if (c) { m = max(m, c); sl = max(sl, i + 1); }
@@ -432,7 +432,8 @@ __global__ void __launch_bounds__(TP_THREADS) k_enc_tables_wg(MicUnit *units) {
         else if (mm == 1 || mm < (n >> 15)) rc = MICD_ERR_INCOMPRESSIBLE;
         uint32_t tl = 0;
         if (rc == MICD_OK) { tl = mic_optimal_table_log(n, ss, u.req_tl); u.table_log = tl; }
-        else u.status = rc;
+        if (rc == MICD_OK && (1u << tl) > u.tab_cap) rc = MICD_INT_GROW;      // (tier 1: the table slabs hold 8192 states)
+        if (rc != MICD_OK) u.status = rc;
         s_misc[0] = (uint32_t)rc; s_misc[1] = tl; s_misc[4] = ss; s_misc[5] = n;
     }
     __syncthreads();
@@ -561,7 +562,7 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
                 if (len < 6) { rc = MICD_ERR_CORRUPT; break; }
                 count = (uint32_t)s_in[2] | ((uint32_t)s_in[3] << 8) | ((uint32_t)s_in[4] << 16) | ((uint32_t)s_in[5] << 24);
                 off = 6;
-                if (count > u.tok_cap) { rc = MICD_ERR_CORRUPT; break; }
+                if (count > u.tok_cap) { rc = u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CORRUPT; break; }   // (tier 1: a small token slab; tier 2 decides)
             }
             // Parse from the staged bytes when that is certain to be identical: the whole blob is staged, or the
             // header ends well inside the stage; otherwise from HBM.
@@ -578,7 +579,11 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
                 }
             }
         } while (0);
-        if (!BIG && rc == MICD_ERR_UNSUPPORTED) { u.flavour = DP_DEFER; return; }
+        if (!BIG && rc == MICD_ERR_UNSUPPORTED) {
+            if (u.tier == 1) { u.status = MICD_INT_GROW; return; }            // (more than 8192 symbols: the count slab is tier 1's)
+            u.flavour = DP_DEFER; return;
+        }
+        if (rc == MICD_OK && (1u << tl) > u.tab_cap) rc = MICD_INT_GROW;       // (tier 1: the decode table slabs hold 8192 states)
         if (rc == MICD_OK) { u.flavour = flavour; u.count = count; u.symbol_len = symbol_len; u.table_log = tl; u.bits_off = off + used; }
         else u.status = rc;
     }

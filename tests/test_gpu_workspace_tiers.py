@@ -1,0 +1,113 @@
+"""GPU tests of the two workspace tiers (mic_session.h): a session starts with slabs sized for ordinary frames (tier 1) and runs a
+batch again in worst-case slabs (tier 2) when a unit reports it needs them -- more tokens than pixels + an eighth (a frame where most
+pixels escape, deltarlecompressu16.go:52-56), or an alphabet past 8192 symbols (depth 14 and up, fseu16.go:57-58).  The retry must
+not change a byte, in either direction, on the session entry points or on the host-pointer ones."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _escape_frame(w=640, h=480, maxv=4095):
+    """Every second column at the top of the range: nearly every pixel is an escape (delimiter + raw value = two tokens a pixel)"""
+    img = np.zeros((h, w), dtype=np.uint16)
+    img[:, ::2] = maxv
+    img[::7, ::3] = maxv // 3
+    return img
+
+
+def _session_round_trip(mic, sess, imgs, maxv, torch):
+    w, h = imgs[0].shape[1], imgs[0].shape[0]
+    stack = np.stack(imgs)
+    units = mic.Session.make_units([(i * w * h, w, h, maxv, 2) for i in range(len(imgs))])
+    d_px = torch.from_numpy(stack.view(np.int16).copy()).cuda()
+    sess.encode_enqueue(d_px.data_ptr(), units)
+    d_blobs, offs, st, _ = sess.encode_finish()
+    host = np.empty(int(offs[-1]), np.uint8)
+    assert C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(d_blobs), C.c_size_t(host.size), 2) == 0
+    return units, host, offs, st
+
+
+def test_escape_heavy_batch_runs_again_in_tier_two_with_the_same_bytes(mic, mico, synth, gpu_ready):
+    torch = pytest.importorskip("torch")
+    w, h, maxv = 640, 480, 4095
+    plain = [synth.xr_like(cols=w, rows=h, depth=12, seed=40 + i) for i in range(3)]
+    sess = mic.Session(4, w * h)
+    try:
+        nbytes, big = sess.workspace_bytes()
+        assert not big and nbytes <= 8 * 4 * w * h * 2                           # tier 1: under eight times the pixels it holds
+        _, host, offs, st = _session_round_trip(mic, sess, plain, maxv, torch)
+        assert not sess.workspace_bytes()[1]                                     # ordinary frames stay in tier 1
+        for k, img in enumerate(plain):
+            rc, want = mico.compress_single_frame(img, maxv, 2)
+            assert st[k] == rc == 0 and host[int(offs[k]):int(offs[k + 1])].tobytes() == want
+        mixed = [plain[0], _escape_frame(w, h, maxv), plain[1]]
+        units, host, offs, st = _session_round_trip(mic, sess, mixed, maxv, torch)
+        assert sess.workspace_bytes()[1]                                         # the escape frame did not fit: the batch ran in tier 2
+        for k, img in enumerate(mixed):
+            rc, want = mico.compress_single_frame(img, maxv, 2)
+            assert st[k] == rc == 0 and host[int(offs[k]):int(offs[k + 1])].tobytes() == want, k
+    finally:
+        sess.close()
+    # decode of the same streams in a fresh session: tier 1 first, the long token stream asks for tier 2
+    fresh = mic.Session(3, w * h)
+    try:
+        assert not fresh.workspace_bytes()[1]
+        d_in = torch.from_numpy(host.copy()).cuda()
+        d_out = torch.zeros(3 * w * h, dtype=torch.int16, device="cuda")
+        fresh.decode_enqueue(d_in.data_ptr(), offs, units, d_out.data_ptr())
+        st = fresh.decode_finish()
+        assert fresh.workspace_bytes()[1]
+        back = d_out.cpu().numpy().view(np.uint16).reshape(3, h, w)
+        for k, img in enumerate(mixed):
+            assert st[k] == 0 and np.array_equal(back[k], img), k
+    finally:
+        fresh.close()
+
+
+def test_sixteen_bit_streams_start_in_tier_two_on_encode_and_grow_on_decode(mic, mico, synth, gpu_ready):
+    torch = pytest.importorskip("torch")
+    w, h, maxv = 512, 300, 65535
+    imgs = [synth.xr_like(cols=w, rows=h, depth=16, seed=60 + i) for i in range(2)]
+    sess = mic.Session(2, w * h)
+    try:
+        units, host, offs, st = _session_round_trip(mic, sess, imgs, maxv, torch)
+        for k, img in enumerate(imgs):
+            rc, want = mico.compress_single_frame(img, maxv, 2)
+            assert st[k] == rc == 0 and host[int(offs[k]):int(offs[k + 1])].tobytes() == want
+    finally:
+        sess.close()
+    fresh = mic.Session(2, w * h)
+    try:
+        d_in = torch.from_numpy(host.copy()).cuda()
+        d_out = torch.zeros(2 * w * h, dtype=torch.int16, device="cuda")
+        fresh.decode_enqueue(d_in.data_ptr(), offs, units, d_out.data_ptr())
+        st = fresh.decode_finish()
+        assert fresh.workspace_bytes()[1]                                        # (a 65536-symbol table does not fit tier 1's 8192 slots)
+        back = d_out.cpu().numpy().view(np.uint16).reshape(2, h, w)
+        for k, img in enumerate(imgs):
+            assert st[k] == 0 and np.array_equal(back[k], img)
+    finally:
+        fresh.close()
+
+
+def test_host_entry_points_grow_without_the_caller_seeing_it(mic, mico, synth, gpu_ready):
+    """PICS batch over host pointers: an escape-heavy image among ordinary ones, then a 16-bit one; bytes as the oracle writes them"""
+    w, h = 640, 480
+    imgs = [synth.xr_like(cols=w, rows=h, depth=12, seed=70), _escape_frame(w, h, 4095), synth.xr_like(cols=w, rows=h, depth=12, seed=71)]
+    res = mic.compress_parallel_strips_batch(imgs, 4095, 4, 2)
+    files = []
+    for img, (st, blob) in zip(imgs, res):
+        rc, want = mico.pics_compress(img, 4095, 4, 2)
+        assert st == rc == 0 and blob.tobytes() == want
+        files.append(want)
+    out = mic.decompress_parallel_strips_batch(files, [(w, h)] * 3)
+    for img, (st, px) in zip(imgs, out):
+        assert st == 0 and np.array_equal(px, img)
+    ct = synth.xr_like(cols=w, rows=h, depth=16, seed=72)
+    rc, want = mico.pics_compress(ct, 65535, 4, 2)
+    assert rc == 0 and mic.compress_parallel_strips(ct, w, h, 65535, 4) == want
+    px, gw, gh = mic.decompress_parallel_strips(want)
+    assert (gw, gh) == (w, h) and np.array_equal(np.asarray(px).reshape(h, w), ct)
