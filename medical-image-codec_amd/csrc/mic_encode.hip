@@ -93,8 +93,15 @@ __device__ __forceinline__ uint32_t tk_half(const uint32_t (&w)[4], int k) { ret
 // its left one (avg(t, t) = t).  With every sample below 2^15 the residuals come two per instruction on the packed VALU.  Their
 // symbols (8 per thread; 16 when every pixel is an escape) go to a 4096-symbol LDS window; a tile that holds an escape is walked
 // in two halves, so the window never holds more.  All 512 threads own 8 window positions.
+
+#ifndef TK_WPS
+#define TK_WPS 6        // waves per SIMD the tokeniser is compiled for (6: three groups per CU, 80 VGPRs)
+#endif
+#ifndef TK_ABL
+#define TK_ABL 0       // timing-only ablations (tools/abl_tok.sh): 1 = no general count loop, 2 = no general write loop
+#endif
 template <int SRC, int PRED = 0>
-__global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units) {
+__global__ void __launch_bounds__(TK_THREADS, TK_WPS) k_enc_tokens_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (!SRC && u.pred != (uint32_t)PRED) return;
     __shared__ __attribute__((aligned(16))) uint16_t xs2[2][TK_WIN + 16];   // per pass parity: [0..5] = 6 symbols before the window, [6..] = new symbols
@@ -105,6 +112,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
     // the delta threshold takes almost every token; the rest goes to HBM atomics
     __shared__ uint32_t s_hist[TK_HWIN];
     __shared__ uint32_t s_tmaxall;
+    __shared__ tk_v4 s_item[TK_THREADS / 64][8];                // per wave: the threads whose positions are written one per lane (phase D)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.mode != (SRC ? 2u : 0u)) return;                    // bare-FSE units (mode 1) bring their own tokens
     if (SRC && u.status != MICD_OK) return;                   // the symbol producer already failed
@@ -165,7 +173,10 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         }
     }
     __syncthreads();
-    // pixels of a tile are fetched one tile ahead (the group otherwise idles through an HBM round trip per tile).
+    // Symbol units (SRC 1: one group per CU on WaveletV2 frames) fetch a tile ahead -- the group otherwise idles through an HBM round
+    // trip per tile.  Frame units do not: the pixels in flight are 12 registers held across the whole tile, which at three groups
+    // per CU (80 registers) cost 23 spilled registers in every tile and 1.2 ms of 4.4 per batch; the other two groups cover the trip.
+    constexpr bool AHEAD = SRC != 0;
     // kind 1: the eight pixels, the eight above them and the one to the left came as vectors (all eight have an upper neighbour, or
     // none has: row 0); kind 2: the thread reads its pixels one by one (the unit's tail, the step from row 0 to row 1, W < 8)
     struct TkFetch { tk_v4 cv, tv; uint32_t lft, tl, tr, x, y, kind; };
@@ -195,7 +206,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         }
         return f;
     };
-    TkFetch nxt = fetch(0);
+    TkFetch nxt = AHEAD ? fetch(0) : TkFetch{};
     MIC_STAMP_BEGIN();
     for (uint32_t tile = 0; tile <= ntiles; tile++) {
         const bool flush = tile == ntiles;
@@ -203,8 +214,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         uint32_t ls[2 * TK_PPT]; uint32_t cnt = 0; int esc = 0;
         bool pk_ok = false; uint32_t pk[4] = { 0u, 0u, 0u, 0u };   // the thread's eight symbols as four packed dwords (the usual case)
         const uint32_t gbase = tile * TP + tid * TK_PPT;
-        const TkFetch f = nxt;
-        nxt = fetch(tile + 1);
+        TkFetch f;
+        if (AHEAD) { f = nxt; nxt = fetch(tile + 1); } else f = fetch(tile);
         if (!flush && gbase < npx) {
             const uint32_t cw[4] = { f.cv.x, f.cv.y, f.cv.z, f.cv.w };
             if (SRC) {
@@ -396,6 +407,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         uint32_t k_in = 0, j_in = 0, rk_in = 0, sj_in = 0;     // state in front of position 0 (D replays the recurrence)
         uint32_t bq = 0xFFFFu;                                  // lit8: position that opens a literal chunk (>= 8: none here)
         uint32_t tsum = 0, jq = 0;
+        const bool cf = V == 0xFFu && !lit8 && !flush && c >= 16;   // counted in closed form, written one position per lane
+        uint32_t itx = 0, ity = 0, itz = 0;
         const uint32_t ex2_lim = g1 + 1;                        // flush: ex2 <=> i3 < g1 + 1 ; ex1 <=> i3 < g1 + 2 ; ex3 <=> i3 < g1
         if (V) {
             // state of the symbol in front of position 0 (index i0 - 1 = ibase - 2)
@@ -407,10 +420,30 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
                 bq = jr ? c - jr : 0u;                           // position q opens a chunk <=> (j + q) % c == 0
                 jq += jr ? 1u : 0u;                              // ceil(j / c): chunks of the stretch opened in front of position 0, + 1
                 tsum = TK_SPT + (bq < TK_SPT ? 1u : 0u);
-            } else {
+            } else if (TK_ABL & 1) tsum = __popc(V);
+            else {
                 uint32_t rk = (k >= 3) ? mod_c(k - 3) : 0u;
                 uint32_t sj = (j >= 1) ? mod_c(j - 1) : 0u;
                 k_in = k; j_in = j; rk_in = rk; sj_in = sj;
+                if (cf) {
+                    // With c >= 16 > 8 a count wraps at most once among eight positions, and only in the run / stretch that comes in
+                    // from the left (one that starts here stays below c), so the loop below has a closed form over the bit masks:
+                    // a same-run symbol owns 2 tokens where its run ends (LAST) and 2 where the run's count wraps; any other symbol
+                    // owns its literal, + 1 where it opens a chunk (stretch start, or the incoming stretch's index wraps).
+                    const uint32_t S8 = SAME & 0xFFu, N8 = ~S8 & 0xFFu;
+                    const uint32_t fr = RS ? (uint32_t)__builtin_ctz(RS) : 8u, fs = STS ? (uint32_t)__builtin_ctz(STS) : 8u;
+                    const uint32_t qw = c - 1 - rk, qs = c - 1 - sj;
+                    const uint32_t cfW = (k >= 3 && qw < fr) ? ((1u << qw) & S8) : 0u;
+                    const uint32_t cfS = STS | ((qs < fs) ? ((1u << qs) & N8) : 0u) | ((j == 0 && fs > 0) ? (1u & N8) : 0u);
+                    tsum = __popc(N8) + __popc(cfS) + 2 * (__popc(S8 & LAST) + __popc(cfW));
+                    // what phase D needs of this thread, packed: SAME | RS << 8 | STS << 16 | SAME & LAST << 24 (eight positions each);
+                    // positions that open a chunk | positions where the incoming run's count wraps << 8 | EM bits 3..12 << 16 | lane << 26;
+                    // (count - 3) % c of the incoming run (one shorter than 3 so far: its count - 3, mod c) | (index - 1) % c of the
+                    // incoming stretch << 16
+                    itx = S8 | ((RS & 0xFFu) << 8) | ((STS & 0xFFu) << 16) | ((S8 & LAST) << 24);
+                    ity = cfS | (cfW << 8) | (((EM >> 3) & 0x3FFu) << 16) | (lane << 26);
+                    itz = (k >= 3 ? rk : c + k - 3) | (sj << 16);
+                } else
 #pragma unroll
                 for (int q = 0; q < TK_SPT; q++) {
                     const uint32_t bit = 1u << q;
@@ -452,6 +485,8 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
         }
         MIC_STAMP_AT(u, 2);
         // ---- D: write ----------------------------------------------------------------------------
+        uint64_t cf_bal = (TK_ABL & 6) ? 0ull : __ballot(cf && tsum != 0);   // (a thread inside a run owns no token)
+        const bool cf_loop = __popcll(cf_bal) > 16;             // too many of them in this wave: the serial walk is cheaper
         if (lit8) {
             if (pos + TK_SPT + 1 <= cap) {
                 if (bq >= TK_SPT) {
@@ -477,7 +512,7 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
                     for (int q = 0; q < TK_SPT; q++) count_tok(v[q + 3]);
                 }
             } else s_ovf = 1;
-        } else if (V) {
+        } else if (V && (!cf || cf_loop) && !(TK_ABL & 2)) {
             bool ovf = false;
             uint32_t k = k_in, j = j_in, rk = rk_in, sj = sj_in;
 #pragma unroll
@@ -522,6 +557,65 @@ __global__ void __launch_bounds__(TK_THREADS, 6) k_enc_tokens_wg(MicUnit *units)
                 }
             }
             if (ovf) s_ovf = 1;
+        }
+        // Threads that are neither eight plain literals nor inside a run (the two ends of a run, a stretch start: a few per wave on
+        // X-ray frames, where every row ends in a run) used to walk their eight positions one after the other while the whole wave
+        // waited.  Their positions are written one per lane instead: up to eight such threads at a time leave their packed masks in
+        // LDS, lane 8 e + q takes position q of thread e; a position's token offset is a popcount over the masks below it.
+        if (cf_bal && !cf_loop) {
+            uint64_t bal = cf_bal;
+            bool pending = cf && tsum != 0;
+            const uint16_t *xw = xs + 3 + (size_t)wave * 64 * TK_SPT;
+            while (bal) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                const bool mine = pending && rank < 8;
+                if (mine) s_item[wave][rank] = tk_v4{itx, ity, itz, pos};
+                // (LDS operations of one wave are carried out in the order they are issued, and the compiler keeps a store and a load of
+                // the same array in program order: no fence -- a release fence here would also wait for the pixel prefetch in flight)
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t nitem = min(8u, (uint32_t)__popcll(bal));
+                const uint32_t e = lane >> 3, q = lane & 7u;
+                if (e < nitem) {
+                    const tk_v4 it = s_item[wave][e];
+                    const uint32_t S8 = it.x & 0xFFu, RSm = (it.x >> 8) & 0xFFu, STm = (it.x >> 16) & 0xFFu, LSm = it.x >> 24;
+                    const uint32_t OPm = it.y & 0xFFu, WRm = (it.y >> 8) & 0xFFu, EMh = (it.y >> 16) & 0x3FFu, src = it.y >> 26;
+                    const uint32_t N8 = ~S8 & 0xFFu, bit = 1u << q, lt = bit - 1u, le = (bit << 1) - 1u;
+                    uint32_t P = it.w + __popc(N8 & lt) + __popc(OPm & lt) + 2 * (__popc(LSm & lt) + __popc(WRm & lt));
+                    const uint32_t xv = xw[src * TK_SPT + q];
+                    bool ovf = false;
+                    if (S8 & bit) {
+                        if (WRm & bit) {
+                            if (P + 1 < cap) { tok[P] = (uint16_t)c; tok[P + 1] = (uint16_t)xv; count_tok(c); count_tok(xv); } else ovf = true;
+                            P += 2;
+                        }
+                        if (LSm & bit) {
+                            const uint32_t rsb = RSm & le;
+                            uint32_t rkq;
+                            if (rsb) rkq = q - (31u - (uint32_t)__clz(rsb)) - 2u;          // a run that began at one of these positions
+                            else { rkq = (it.z & 0xFFFFu) + q + 1; if (rkq >= c) rkq -= c; }
+                            const uint32_t rem = rkq + 3;                                 // (k - 3) % c + 3
+                            if (P + 1 < cap) { tok[P] = (uint16_t)rem; tok[P + 1] = (uint16_t)xv; count_tok(rem); count_tok(xv); } else ovf = true;
+                        }
+                    } else {
+                        const uint32_t lit = P + ((OPm >> q) & 1u);
+                        if (lit < cap) { tok[lit] = (uint16_t)xv; count_tok(xv); } else ovf = true;
+                        const uint32_t ssb = STm & le;
+                        uint32_t sjq;
+                        if (ssb) sjq = q - (31u - (uint32_t)__clz(ssb));
+                        else { sjq = (it.z >> 16) + q + 1; if (sjq >= c) sjq -= c; }
+                        // the chunk ends here when the next symbol starts a same-run (x[q+1] != x[q], x[q+1] == x[q+2] == x[q+3]) or opens a chunk
+                        if (((EMh >> q) & 7u) == 6u || sjq + 1 == c) {
+                            const uint32_t qlen = sjq + 1;
+                            if (lit >= qlen && lit - qlen < cap) { tok[lit - qlen] = (uint16_t)(mid + qlen); count_tok(mid + qlen); } else ovf = true;
+                        }
+                    }
+                    if (ovf) s_ovf = 1;
+                }
+                const uint64_t done = __ballot(mine);
+                bal &= ~done;
+                pending = pending && !mine;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         MIC_STAMP_AT(u, 3);
         // ---- E: carry --------------------------------------------------------------------------------
