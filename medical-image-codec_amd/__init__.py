@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmic_hip.so")
+LIB_PATH = os.environ.get("MIC_HIP_LIB") or os.path.join(_HERE, "libmic_hip.so")   # (MIC_HIP_LIB: an A/B build of the same ABI, tools/ only)
 
 MIC_OK = 0
 MIC_ERR_ARGS = -1

@@ -97,7 +97,16 @@ template <class T> __device__ __forceinline__ mic_gp<T> mic_g(T *p) { return (mi
 #else
 #define MIC_STAMP_BEGIN() do { } while (0)
 #define MIC_STAMP_AT(u, k) do { } while (0)
+
 #endif
+
+// A barrier across which threads of one work-group hand GLOBAL memory to each other (one thread's stores, another's loads).
+// __syncthreads() and __threadfence_block() emit no wait for outstanding stores and no L1 invalidate at work-group scope on gfx950
+// (the memory model leaves the ordering to the CU's L1; the ISA shows the store, the barrier and the load with nothing in between).
+// Where the hand-off is between threads, not only within one, the writers wait for their stores to be acknowledged and the readers
+// drop their L1 lines: it costs nothing measurable and does not rest on how the L1 orders a store with a later load that misses.
+#define MIC_GROUP_HANDOFF() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); \
+                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
 
 __device__ __forceinline__ int mic_len16(uint32_t v) { return v ? 32 - __clz(v) : 0; }
 // gradPredict (deltagradcompressu16.go:147-167): avg(W, N) + clamp((NE - NW) >> 3, +-(|W - NW| + |N - NW|) / 2); no gradient, no correction

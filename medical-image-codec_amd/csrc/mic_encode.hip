@@ -780,25 +780,36 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 // LDS: stateTable as u16 (state - 2^tl).  grid = units, block = 1024, dynamic LDS = 2 << tl.
 #define TE_THREADS 512              // two groups per CU (128 VGPRs each): the fix-up stalls of one overlap the other's work
 #define TE_WAVES 8
-#define TE_BLK 32                 // tokens per 64-byte block
-#define TE_RGRP 4                 // blocks per fix-up record
-#define TE_WARM 12                // blocks of the predecessor's range walked as warm-up
+#define TE_BLK 64                 // the largest block a walk reads at a time, in tokens (te_encode: BLK)
+#ifndef TE_NARROW_WPS
+#define TE_NARROW_WPS 6          // waves per SIMD the two-state instance is compiled for (6: three groups per CU; it needs 64 registers)
+#endif
+#ifndef TE_BLK2
+#define TE_BLK2 64                // tokens per block of the one- and two-state walks
+#endif
+#ifndef TE_ABL
+#define TE_ABL 0         // timing-only ablations: 1 = every block read comes from the unit's first 4 KiB, 2 = the pack pass stores nothing
+#endif
+#define TE_ABL_BASE(b) ((TE_ABL & 1) ? ((b) & 2047u) : (b))
 #define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
 
-// One block of 32 tokens / 32 recorded states as four 16-byte vectors.
-struct TeBlk { uint4 v[4]; };
-__device__ __forceinline__ TeBlk te_load(mic_gp<const uint16_t> p) {
-    TeBlk b; const mic_gp<const tk_v4> q = (mic_gp<const tk_v4>)p;
+// One block of B tokens as 16-byte vectors.
+template <int B> struct TeBlkT { uint4 v[B / 8]; };
+template <int B>
+__device__ __forceinline__ TeBlkT<B> te_load(mic_gp<const uint16_t> p) {
+    TeBlkT<B> b; const mic_gp<const tk_v4> q = (mic_gp<const tk_v4>)p;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const tk_v4 x = q[i]; b.v[i] = make_uint4(x.x, x.y, x.z, x.w); }
+    for (int i = 0; i < B / 8; i++) { const tk_v4 x = q[i]; b.v[i] = make_uint4(x.x, x.y, x.z, x.w); }
     return b;
 }
-__device__ __forceinline__ uint32_t te_get(const TeBlk &b, int j) {   // j compile-time after unrolling
+template <int B>
+__device__ __forceinline__ uint32_t te_get(const TeBlkT<B> &b, int j) {   // j compile-time after unrolling
     const uint4 &v = b.v[j >> 3];
     const uint32_t w = ((j >> 1) & 3) == 0 ? v.x : ((j >> 1) & 3) == 1 ? v.y : ((j >> 1) & 3) == 2 ? v.z : v.w;
     return (j & 1) ? (w >> 16) : (w & 0xFFFF);
 }
-__device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
+template <int B>
+__device__ __forceinline__ void te_set(TeBlkT<B> &b, int j, uint32_t x) {
     uint4 &v = b.v[j >> 3];
     uint32_t &w = ((j >> 1) & 3) == 0 ? v.x : ((j >> 1) & 3) == 1 ? v.y : ((j >> 1) & 3) == 2 ? v.z : v.w;
     w = (j & 1) ? ((w & 0xFFFFu) | (x << 16)) : ((w & 0xFFFF0000u) | (x & 0xFFFF));
@@ -811,6 +822,11 @@ __device__ __forceinline__ void te_set(TeBlk &b, int j, uint32_t x) {
 template <int N, bool RANS, bool TTL, int T, bool FS>   // FS: the LDS state table holds whole states (they fit 16 bits up to tableLog 15)
 __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                           uint16_t *s_E, uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {   // s_E: T x N end states
+    // tokens per block: the two-state walk (the usual flavour) reads a whole 128-byte line at a time (two 64-byte halves read apart were two
+    // fetches: the line does not survive in a cache between them); the wider walks have no registers for that
+    constexpr int BLK = (N == 2 && !RANS && TTL) ? TE_BLK2 : 32;
+    constexpr uint32_t RGRP = 128 / BLK, WARM = 384 / BLK;   // blocks per fix-up record (128 tokens); blocks of the predecessor's range walked as warm-up
+    typedef TeBlkT<BLK> TeBlk;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
     const mic_gp<const uint16_t> src = mic_g((const uint16_t *)u.tok);
@@ -824,7 +840,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     const uint32_t lead = (uint32_t)((uintptr_t)bits_base & 15);          // the bit grid starts at a 16-byte boundary: the pack pass stores pairs of 64-bit units
     const mic_gp<uint32_t> words = (mic_gp<uint32_t>)(bits_base - lead);
     const uint32_t words_cap = (u.blob_cap - 6 - hdr_len - 8) / 4;
-    const uint32_t nblk = (n + TE_BLK - 1) / TE_BLK;
+    const uint32_t nblk = (n + BLK - 1) / BLK;
     const uint32_t per = (nblk + T - 1) / T;
     const uint32_t b_hi = (tid * per < nblk) ? nblk - tid * per : 0;
     const uint32_t b_lo = (b_hi > per) ? b_hi - per : 0;
@@ -847,12 +863,12 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         }
     };
     MIC_STAMP_BEGIN();
-    // Per group of TE_RGRP blocks (128 tokens) the walk leaves a record in HBM: the N states after the group
+    // Per group of RGRP blocks (128 tokens) the walk leaves a record in HBM: the N states after the group
     // (u16, minus 2^tl) and the bits the group emits, one aligned vector store.  Fix-up compares and replaces
     // records; packing needs none of them (it walks again from the true start states), so tokens are read
     // twice and states never stored.  Record slot = tid * gper + group index inside the thread's range.
     constexpr uint32_t RWP = (N == 1) ? 2u : 2u * N;       // u16 per record: N states, the bit count, padding
-    const uint32_t gper = (per + TE_RGRP - 1) / TE_RGRP;
+    const uint32_t gper = (per + RGRP - 1) / RGRP;
     const mic_gp<uint32_t> rec32 = (mic_gp<uint32_t>)stv + (size_t)tid * gper * (RWP / 2);
     auto rec_store = [&](uint32_t g, const uint32_t (&stw)[N], uint32_t bits) {
         uint32_t w[RWP / 2];
@@ -873,19 +889,20 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         bits = (w[N >> 1] >> (16 * (N & 1))) & 0xFFFFu;
     };
     auto walk_block = [&](uint32_t base, uint32_t (&stw)[N]) -> uint32_t {
-        const TeBlk tk = te_load(src + base);
+        const TeBlk tk = te_load<BLK>(src + TE_ABL_BASE(base));
         uint32_t bits = 0;
-        if (base + TE_BLK <= n) {                                   // every block but the stream's last: no per-token bound
+        if (base + BLK <= n) {                                   // every block but the stream's last: no per-token bound
 #pragma unroll
-            for (int j = TE_BLK - 1; j >= 0; j--) {
+            for (int j = BLK - 1; j >= 0; j--) {
                 const int k = j & (N - 1);
                 uint32_t nb;
                 stw[k] = step(stw[k], te_get(tk, j), nb);
                 bits += nb;
+                if (BLK > 32 && (j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
-            for (int j = TE_BLK - 1; j >= 0; j--) {
+            for (int j = BLK - 1; j >= 0; j--) {
                 if (base + (uint32_t)j < n) {
                     const int k = j & (N - 1);
                     uint32_t nb;
@@ -899,11 +916,11 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     uint32_t st[N];
 #pragma unroll
     for (int k = 0; k < N; k++) st[k] = size;        // tANS: 1 << tl; rANS: x = 0, kept as xL = x + 2^tl
-    // Warm-up: walks merge within ~100 symbols, so walking the last TE_WARM blocks of the predecessor's range first
+    // Warm-up: walks merge within ~100 symbols, so walking the last WARM blocks of the predecessor's range first
     // (nothing recorded) almost always lands on the true start state, and the fix-up below only has to confirm it.
     if (tid > 0 && b_hi > b_lo) {
-        const uint32_t w_hi = min(b_hi + TE_WARM, nblk);
-        for (uint32_t b = w_hi; b > b_hi; b--) (void)walk_block((b - 1) * TE_BLK, st);
+        const uint32_t w_hi = min(b_hi + WARM, nblk);
+        for (uint32_t b = w_hi; b > b_hi; b--) (void)walk_block((b - 1) * BLK, st);
     }
     uint32_t assumed[N];
 #pragma unroll
@@ -911,7 +928,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     uint32_t mybits = 0;
     for (uint32_t g = 0, b = b_hi; b > b_lo; g++) {
         uint32_t bits = 0;
-        for (uint32_t r = 0; r < TE_RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * TE_BLK, st);
+        for (uint32_t r = 0; r < RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * BLK, st);
         mybits += bits;
         rec_store(g, st, bits);
     }
@@ -940,7 +957,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                 atomicMax(&u.dbg[14], g + 1);                             // longest re-walk in groups
 #endif
                 uint32_t bits = 0;
-                for (uint32_t r = 0; r < TE_RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * TE_BLK, st2);
+                for (uint32_t r = 0; r < RGRP && b > b_lo; r++, b--) bits += walk_block((b - 1) * BLK, st2);
                 uint32_t old_st[N], old_bits;
                 rec_load(g, old_st, old_bits);
                 merged = true;
@@ -1024,6 +1041,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     uint64_t pend = 0; bool have_pend = false;                            // the even unit of a pair, waiting for its odd partner
     typedef unsigned long long te_u2 __attribute__((ext_vector_type(2)));
     auto emit = [&](uint64_t v) {                                          // unit q is complete (or the thread's last, partial one)
+        if (TE_ABL & 2) { q++; return; }
         if (q == first_q && !own_first) { lead_val = v; have_lead = true; }
         else if (q & 1u) {
             if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(mic_gp<te_u2>)(words64 + (q - 1)) = pr; have_pend = false; }
@@ -1039,11 +1057,11 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         // Four tokens (<= 64 bits) are gathered branch-free before they meet the accumulator: the test "does a 64-bit unit fill up"
         // is a divergent branch that some lane takes at almost every token, so it is made once per four of them.
         for (uint32_t b = b_hi; b > b_lo; b--) {
-            const uint32_t base = (b - 1) * TE_BLK;
-            const TeBlk tk = te_load(src + base);
-            const bool whole = base + TE_BLK <= n;
+            const uint32_t base = (b - 1) * BLK;
+            const TeBlk tk = te_load<BLK>(src + base);
+            const bool whole = base + BLK <= n;
 #pragma unroll
-            for (int j4 = TE_BLK / 4 - 1; j4 >= 0; j4--) {
+            for (int j4 = BLK / 4 - 1; j4 >= 0; j4--) {
                 uint64_t t4 = 0; uint32_t f4 = 0;
 #pragma unroll
                 for (int jj = 3; jj >= 0; jj--) {
@@ -1070,8 +1088,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     }
     if (mybits > 0 && filled > 0) emit(acc);                             // the thread's last, partial unit
     if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
-    __threadfence_block();
-    __syncthreads();
+    MIC_GROUP_HANDOFF();                                   // (every unit is in L2 before anything is OR-ed into it)
     if (have_lead && lead_val) (void)__hip_atomic_fetch_or(&words64[first_q], (unsigned long long)lead_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_block();
     __syncthreads();
@@ -1111,14 +1128,24 @@ __device__ __forceinline__ int te_small_class(const MicUnit &u) {
 // widest flavour a unit of the launch may ask for (2 when the whole batch is two-state: the 512-thread instance then takes 50 KiB
 // and THREE groups share a CU -- the kernel waits on LDS round trips most of its time, SQ_WAIT_ANY 0.73 of its wave cycles --
 // at 80 VGPRs; 8 otherwise).
-template <int TLHI, int T, int TTS>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16; threads; LDS coding records
-__global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *units, int e_states) {
+// WIDTH (the 512-thread instance up to tableLog 13 only): 1 = units that ask for two states and whose coding records fit the LDS:
+// ONE walk in the kernel, two groups per CU, no scratch; 2 = every other unit (one, four, eight states, rANS, alphabets past 4096
+// symbols) and the two-state units whose first attempt failed (they start over there), compiled for one group per CU.  One instance for both had the wide walks spill 60 registers at 80 and
+// charged the two-state batches a 364-byte scratch frame per lane.  0 = every unit (the other instances: registers are not tight).
+template <int TLHI, int T, int TTS, int WIDTH = 0>      // table-size class of the launch: tableLog <= 13, 14, 15 or 16; threads; LDS coding records
+// Waves per SIMD the instance is compiled for = what its LDS lets a CU hold: three 512-thread groups up to tableLog 13 (80 VGPRs:
+// the two-state walk needs 60; the four- and eight-state walks spill there), two at 14, one at 15 and 16 (no register limit worth
+// the name: the WaveletV2 four-state walk at tableLog 16 used to run on the 80 registers of the first class, 47 of them spilled).
+__global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2 : TE_NARROW_WPS) : 2) k_enc_tans_wg(MicUnit *units, int e_states) {
     constexpr uint32_t tl_lo = (TLHI <= 13) ? 5u : (uint32_t)TLHI, tl_hi = (uint32_t)TLHI;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_stab[];
     uint16_t *const s_E = s_stab + (1u << TLHI) + (TLHI <= 15 ? (uint32_t)TTS * 4u : 0u);
     __shared__ uint32_t s_scan[(T / 64) + 2];
     MicUnit &u = units[blockIdx.x];
-    if (u.status != MICD_OK || u.nstates_used != 0) return;
+    if (u.status != MICD_OK) return;
+    const bool handed = u.nstates_used == -2;                              // the two-state instance gave up on its first attempt (below)
+    if (u.nstates_used != 0 && !(WIDTH == 2 && handed)) return;
+    if (WIDTH != 0 && ((u.nstates != 2 || u.symbol_len > TTS || handed) ? 2 : 1) != WIDTH) return;   // (1: two states, coding records in LDS)
     if ((u.nstates == 108 ? 8 : (int)u.nstates) > e_states) { if (threadIdx.x == 0) u.status = MICD_ERR_INTERNAL; return; }   // (the launcher sizes the LDS for e_states)
     const uint32_t tl = u.table_log;
     if (tl < tl_lo || tl > tl_hi) return;
@@ -1146,13 +1173,15 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
         uint32_t total_bytes = 0;
         if (rc == MICD_OK) {
             if (TLHI <= 15 && ttl) {
-                if (rans) te_encode<8, true, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 8) te_encode<8, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
-                else if (lanes == 4) te_encode<4, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                if (WIDTH != 1 && rans) te_encode<8, true, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (WIDTH != 1 && lanes == 8) te_encode<8, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (WIDTH != 1 && lanes == 4) te_encode<4, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (lanes == 2) te_encode<2, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                else if (WIDTH == 1) rc = MICD_ERR_INTERNAL;                            // (not reached: the two-state instance hands its fall-backs over)
                 else te_encode<1, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             } else {
-                if (rans) te_encode<8, true, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+                if (WIDTH == 1) rc = MICD_ERR_INTERNAL;                                 // (not reached: such units go to the wide instance)
+                else if (rans) te_encode<8, true, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (lanes == 8) te_encode<8, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (lanes == 4) te_encode<4, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (lanes == 2) te_encode<2, false, false, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
@@ -1177,6 +1206,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 6 : 4) k_enc_tans_wg(MicUnit *un
         if (tid == 0) { u.count = (uint32_t)rc; u.bits_off = total_bytes; u.flavour = lanes; }   // probe: why the attempt failed
         if (rc == MICD_ERR_CAPACITY && u.tier == 1) rc = MICD_INT_GROW;               // (the staging blob is tier 1's)
         if (lanes == 1 || rc == MICD_ERR_CAPACITY || rc == MICD_INT_GROW || single) { if (tid == 0) u.status = rc; return; }
+        if (WIDTH == 1) { if (tid == 0) u.nstates_used = -2; return; }        // the one-state attempt is the wide instance's (it starts over)
         __syncthreads();
     }
 }
@@ -1244,7 +1274,8 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     mic_launch_enc_tables(d_units, n, stream);
     static MicPerDeviceOnce once;
     once.run([] {
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -1252,7 +1283,8 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     const int es = (variant & MIC_VARIANT_NARROW) ? 2 : 8;                      // widest flavour in the batch -> end-state area
     const unsigned eb = TE_THREADS * (unsigned)es * 2u, eb1 = 64u * (unsigned)es * 2u;
     if (t) t->mark("k_enc_tans_wg<13>");
-    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 1>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + TE_THREADS * 2u * 2u, stream, d_units, 2);
+    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 2>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
     if (t) t->mark("k_enc_tans_wg<13, one wave>");
     hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8 + eb1, stream, d_units, es);
     hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8 + eb1, stream, d_units, es);

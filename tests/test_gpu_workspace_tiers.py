@@ -111,3 +111,17 @@ def test_host_entry_points_grow_without_the_caller_seeing_it(mic, mico, synth, g
     assert rc == 0 and mic.compress_parallel_strips(ct, w, h, 65535, 4) == want
     px, gw, gh = mic.decompress_parallel_strips(want)
     assert (gw, gh) == (w, h) and np.array_equal(np.asarray(px).reshape(h, w), ct)
+
+
+@pytest.mark.parametrize("flavour", [1, 2, 4, 8, 108])
+def test_fse_stage_is_the_same_stream_call_after_call(mic, mico, synth, gpu_ready, flavour):
+    """Determinism of the 512-thread tANS encoder: its threads hand end states, fix-up records and the bits that reach into a
+    neighbour's 64-bit unit to each other; a missed hand-off shows as a stream that changes from call to call (a development build
+    did, for one-state streams, one call in two).  Several lengths, several calls each, every stream compared with the oracle's."""
+    tok = mico.delta_rle_compress(synth.xr_like(cols=500, rows=180, depth=12, seed=17), 4095)
+    for n in (tok.size, 65536, 60000, 40000, 20000):
+        t = tok[:n].copy()
+        rc, want = mico.fse_compress(t, flavour)
+        assert rc == 0
+        for _ in range(4):
+            assert mic.fse_compress_u16(t, flavour) == want, n
