@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(128) k_dec_predict2(MicUnit *units, int w_lo, 
                     const pr_gu16 dst = px + sc[k].p;
                     const uint32_t cnt = ((uint32_t)sc[k].cg == cmax - 1) ? min(8u, crem) : 8u;
 #if !(defined(P2_ABL) && (P2_ABL & 4))
-                    if (cnt == 8) { pr_v4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *(__attribute__((address_space(1))) PrQ *)dst = w; }
+                    if (cnt == 8) { pr_v4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *(__attribute__((address_space(1))) PrQ *)dst = w; }   // (a non-temporal store here: 3.3 -> 4.0 ms)
                     else { const uint32_t d[4] = { v.x, v.y, v.z, v.w }; pr_store_cnt<8>(dst, d, (int)cnt); }
 #endif
                 }
