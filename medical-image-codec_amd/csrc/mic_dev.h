@@ -100,11 +100,11 @@ template <class T> __device__ __forceinline__ mic_gp<T> mic_g(T *p) { return (mi
 
 #endif
 
-// A barrier across which threads of one work-group hand GLOBAL memory to each other (one thread's stores, another's loads).
-// __syncthreads() and __threadfence_block() emit no wait for outstanding stores and no L1 invalidate at work-group scope on gfx950
-// (the memory model leaves the ordering to the CU's L1; the ISA shows the store, the barrier and the load with nothing in between).
-// Where the hand-off is between threads, not only within one, the writers wait for their stores to be acknowledged and the readers
-// drop their L1 lines: it costs nothing measurable and does not rest on how the L1 orders a store with a later load that misses.
+// A barrier across which threads of one work-group hand GLOBAL memory to each other where the order matters to something outside the
+// group's own L1 -- the tANS encoder's plain stores of 64-bit units, then the atomic ORs other threads make into them (executed at L2).
+// __syncthreads() / __threadfence_block() emit no wait for outstanding stores at work-group scope on gfx950 (the memory model leaves
+// that order to the CU's L1, which is enough for loads, not for an L2 atomic that could overtake a store still in flight): the writers
+// wait for their stores to be acknowledged, the readers drop their L1 lines.
 #define MIC_GROUP_HANDOFF() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); \
                                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
 

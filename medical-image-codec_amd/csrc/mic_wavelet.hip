@@ -6,8 +6,8 @@
 // rows then columns, AVX2 over 8-column blocks (wavelet_simd_amd64.s).  Here every output sample is
 // written straight from the <= 5 input samples it depends on,
 //     d[i] = x[2i+1] - ((x[2i] + x[2i+2]) >> 1)        s[i] = x[2i] + ((d[i-1] + d[i] + 2) >> 2)
-// with the reference's boundary rules, so a pass is one out-of-place, fully parallel kernel (row pass
-// A -> B, column pass B -> A, both de-interleaving on the fly) and there is no serial dependence at all.
+// with the reference's boundary rules, so there is no serial dependence at all; a LEVEL is one kernel (k_wv_fwd2d / k_wv_inv2d:
+// rows and columns over a tile in LDS, de-interleaving on the fly, the smooth plane handed from level to level in a scratch plane).
 // The subband scan is a closed-form index map, so collect + zigzag + escape + max is one pass with a
 // prefix sum for the rare escapes.  RLE / FSE reuse the unit-codec kernels (mode 2 / mode 1 units).
 #include "mic_session.h"
@@ -61,56 +61,6 @@ __device__ __forceinline__ int32_t wv_sample(Get c, int n, int k) {
     return c(n_low + i) + ((l + r) >> 1);
 }
 
-// One thread per PAIR of outputs (smooth i, detail i): both come from the same five inputs x[2i-2 .. 2i+2].  A group works on a
-// block of rows (rows pass: WV_RPB rows of 256 pairs) or on a strip of pairs down 256 columns (columns pass: WV_SP pairs, the
-// window x[2i], d[i-1] carried in registers: two loads per pair instead of five) -- a group per single row was bound by the rate
-// at which groups are dispatched (5.5 million of them per transform), not by memory.  No division anywhere.
-// FROM_U16: level 0 reads the 16-bit pixels themselves (no widening pass); TO_U16: the last inverse pass stores 16-bit pixels.
-#define WV_RPB 8
-#define WV_SP 16
-// rows of the r x c region: src -> dst, de-interleaved [low | high]   (waveletu16.go:170-182)
-template <bool FROM_U16>
-__global__ void __launch_bounds__(256) k_wv_fwd_rows(const void *__restrict__ src_, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
-    const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (i >= n_low) return;
-    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int y0 = (int)blockIdx.y * WV_RPB; y0 < r; y0 += (int)gridDim.y * WV_RPB)
-#pragma unroll 4
-            for (int y = y0; y < min(y0 + WV_RPB, r); y++) {
-                const size_t ro = (size_t)f * fs + (size_t)y * stride;
-                int32_t sv, dv = 0;
-                if (FROM_U16) { const uint16_t *row = (const uint16_t *)src_ + ro; auto x = [&](int j) { return (int32_t)row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
-                else { const int32_t *row = (const int32_t *)src_ + ro; auto x = [&](int j) { return row[j]; }; sv = wv_s(x, c, i); if (2 * i + 1 < c) dv = wv_d(x, c, i); }
-                dst[ro + i] = sv;
-                if (2 * i + 1 < c) dst[ro + n_low + i] = dv;
-            }
-}
-// columns of the r x c region   (waveletu16.go:183-208): a thread walks WV_SP pairs down its column
-__global__ void __launch_bounds__(256) k_wv_fwd_cols(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
-    const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (xcol >= c) return;
-    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int i0 = (int)blockIdx.y * WV_SP; i0 < n_low; i0 += (int)gridDim.y * WV_SP) {
-            const int32_t *col = src + (size_t)f * fs + xcol;
-            int32_t *o = dst + (size_t)f * fs + xcol;
-            auto x = [&](int j) { return col[(size_t)j * stride]; };
-            int32_t x2i = x(2 * i0), dprev = (i0 > 0) ? wv_d(x, r, i0 - 1) : 0;
-            const int i1 = min(i0 + WV_SP, n_low);
-            for (int i = i0; i < i1; i++) {
-                int32_t d_right, xe2 = x2i;
-                const bool has_d = 2 * i + 1 < r;
-                if (has_d) {                                               // wv_d(i) with x[2i] from the window
-                    const int32_t xo = x(2 * i + 1);
-                    if (2 * i + 2 < r) xe2 = x(2 * i + 2);
-                    d_right = xo - ((x2i + xe2) >> 1);
-                } else d_right = (i > 0) ? dprev : 0;
-                const int32_t d_left = (i > 0) ? dprev : d_right;
-                o[(size_t)i * stride] = x2i + ((d_left + d_right + 2) >> 2);   // wv_s(i)
-                if (has_d) { o[(size_t)(n_low + i) * stride] = d_right; dprev = d_right; }
-                x2i = xe2;
-            }
-        }
-}
 // inverse: columns first, then rows   (waveletu16.go:213-257); a thread restores samples 2i and 2i+1 of its line
 template <typename Get>
 __device__ __forceinline__ void wv_pair(Get cf, int n, int i, int32_t &ev, int32_t &od) {
@@ -120,56 +70,149 @@ __device__ __forceinline__ void wv_pair(Get cf, int n, int i, int32_t &ev, int32
     od = 0;
     if (2 * i + 1 < n) { const int32_t rr = (2 * i + 2 < n) ? wv_even(cf, n, i + 1) : ev; od = cf(n_low + i) + ((ev + rr) >> 1); }
 }
-__global__ void __launch_bounds__(256) k_wv_inv_cols(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int r, int c, int stride, size_t fs, int nf) {
-    const int n_low = (r + 1) / 2, xcol = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (xcol >= c) return;
-    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int i0 = (int)blockIdx.y * WV_SP; i0 < n_low; i0 += (int)gridDim.y * WV_SP) {
-            const int32_t *col = src + (size_t)f * fs + xcol;
-            int32_t *o = dst + (size_t)f * fs + xcol;
-            auto cf = [&](int j) { return col[(size_t)j * stride]; };
-            if (r < 2) { o[0] = cf(0); continue; }
-            // even sample i = c(i) - ((d(i-1) + d(i) + 2) >> 2) with the edge rules of wv_even; odd sample i = d(i) + ((even i + even i+1) >> 1):
-            // the strip carries d(i-1) and even(i) down the column and looks one even sample ahead
-            const int i1 = min(i0 + WV_SP, n_low);
-            int32_t dprev = (i0 > 0) ? cf(n_low + i0 - 1) : 0;
-            int32_t dcur = 0, ev;
-            {
-                const bool has_d = 2 * i0 + 1 < r;
-                if (has_d) dcur = cf(n_low + i0);
-                const int32_t d_right = has_d ? dcur : ((i0 > 0) ? dprev : 0), d_left = (i0 > 0) ? dprev : d_right;
-                ev = cf(i0) - ((d_left + d_right + 2) >> 2);
+// ---- one level of the transform in ONE pass -----------------------------------------------------------------------------------
+// Rows pass and columns pass fused over a tile kept in LDS: a level reads its input once and writes its four subbands once (level 0:
+// 2 + 4 bytes per sample instead of 2 + 4 + 4 + 4; the two-pass kernels of rounds 1-2 moved 19 N bytes per transform, these move 9 N:
+// 14.3 -> 11.4 ms for 256 CR frames both ways -- the tile's index arithmetic, not memory, is what is left).
+// A tile is WT_W x WT_H output PAIRS (2 WT_W x 2 WT_H input samples) + the three samples of context the lifting reaches to on
+// either axis; the per-sample rules are the ones above (wv_s, wv_d, wv_pair) over accessors that map global indices into the tile,
+// so the boundary handling is theirs.  The detail subbands go to their Mallat places in `a` (row stride `stride`); the smooth
+// subband -- the next level's input -- goes to a compact scratch plane (`ll`, row stride = its width), except the last level's,
+// which goes to the top-left corner of `a`: nothing is read and written in the same buffer by one launch.
+#define WT_W 64
+#define WT_H 16
+template <bool FROM_U16>
+__global__ void __launch_bounds__(256) k_wv_fwd2d(const void *__restrict__ src_, int sstride, size_t sfs, int32_t *__restrict__ a, int stride, size_t fs,
+                                                  int32_t *__restrict__ ll, int llstride, size_t llfs, int r, int c, int nf) {
+    constexpr int IW = 2 * WT_W + 3, IH = 2 * WT_H + 3;
+    __shared__ int32_t s_in[IH][IW + 1];
+    __shared__ int32_t s_lo[IH][WT_W], s_hi[IH][WT_W];
+    const int tid = (int)threadIdx.x;
+    const int nlc = (c + 1) / 2, nlr = (r + 1) / 2;
+    const int I0 = (int)blockIdx.x * WT_W, Y0 = (int)blockIdx.y * WT_H;
+    const int j0 = 2 * I0 - 2, y0 = 2 * Y0 - 2;
+    // a tile whose every sample has both neighbours on an axis takes the lifting without the boundary rules there
+    const bool in_x = I0 > 0 && 2 * (I0 + WT_W) + 2 < c, in_y = Y0 > 0 && 2 * (Y0 + WT_H) + 2 < r;
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z) {
+        for (int idx = tid; idx < IH * IW; idx += 256) {
+            const int ly = idx / IW, lx = idx - ly * IW, gy = y0 + ly, gx = j0 + lx;
+            int32_t v = 0;
+            if (gy >= 0 && gy < r && gx >= 0 && gx < c) {
+                const size_t o = (size_t)f * sfs + (size_t)gy * sstride + gx;
+                v = FROM_U16 ? (int32_t)((const uint16_t *)src_)[o] : ((const int32_t *)src_)[o];
             }
-            for (int i = i0; i < i1; i++) {
-                o[(size_t)(2 * i) * stride] = ev;
-                if (2 * i + 1 >= r) break;                                 // (the line's last sample was an even one)
-                int32_t evn = ev, dnext = 0;
-                if (2 * i + 2 < r) {                                       // even sample i + 1
-                    const bool has_d = 2 * (i + 1) + 1 < r;
-                    if (has_d) dnext = cf(n_low + i + 1);
-                    const int32_t d_right = has_d ? dnext : dcur;          // (i + 1 > 0: the left neighbour d(i) exists)
-                    evn = cf(i + 1) - ((dcur + d_right + 2) >> 2);
-                }
-                o[(size_t)(2 * i + 1) * stride] = dcur + ((ev + evn) >> 1);
-                dprev = dcur; dcur = dnext; ev = evn;
+            s_in[ly][lx] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < IH * WT_W; idx += 256) {                      // rows of the tile (waveletu16.go:170-182)
+            const int ly = idx / WT_W, li = idx - ly * WT_W, gy = y0 + ly, gi = I0 + li;
+            if (gy < 0 || gy >= r || gi >= nlc) continue;
+            if (in_x) {
+                const int32_t *x = &s_in[ly][2 * li];                            // x[2] = sample 2 gi
+                const int32_t dl = x[1] - ((x[0] + x[2]) >> 1), dr = x[3] - ((x[2] + x[4]) >> 1);
+                s_lo[ly][li] = x[2] + ((dl + dr + 2) >> 2); s_hi[ly][li] = dr;
+                continue;
+            }
+            auto x = [&](int j) { return s_in[ly][j - j0]; };
+            s_lo[ly][li] = wv_s(x, c, gi);
+            if (2 * gi + 1 < c) s_hi[ly][li] = wv_d(x, c, gi);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * WT_W * WT_H; idx += 256) {                // columns (:183-208): both halves of the rows' output
+            const int lp = idx / (2 * WT_W), col = idx - lp * (2 * WT_W), hi = col >= WT_W, li = hi ? col - WT_W : col;
+            const int gp = Y0 + lp, gi = I0 + li;
+            if (gp >= nlr || gi >= nlc || (hi && 2 * gi + 1 >= c)) continue;
+            if (in_y) {
+                const int32_t (*p)[WT_W] = hi ? s_hi : s_lo;
+                const int b = 2 * lp;                                            // row b + 2 = sample 2 gp
+                const int32_t x0 = p[b][li], x1 = p[b + 1][li], x2 = p[b + 2][li], x3 = p[b + 3][li], x4 = p[b + 4][li];
+                const int32_t dl = x1 - ((x0 + x2) >> 1), dr = x3 - ((x2 + x4) >> 1), sv = x2 + ((dl + dr + 2) >> 2);
+                if (hi) a[(size_t)f * fs + (size_t)gp * stride + nlc + gi] = sv;
+                else ll[(size_t)f * llfs + (size_t)gp * llstride + gi] = sv;
+                a[(size_t)f * fs + (size_t)(nlr + gp) * stride + (hi ? nlc : 0) + gi] = dr;
+                continue;
+            }
+            auto x = [&](int j) { return hi ? s_hi[j - y0][li] : s_lo[j - y0][li]; };
+            const int32_t sv = wv_s(x, r, gp);
+            if (hi) a[(size_t)f * fs + (size_t)gp * stride + nlc + gi] = sv;
+            else ll[(size_t)f * llfs + (size_t)gp * llstride + gi] = sv;
+            if (2 * gp + 1 < r) a[(size_t)f * fs + (size_t)(nlr + gp) * stride + (hi ? nlc : 0) + gi] = wv_d(x, r, gp);
+        }
+        __syncthreads();
+    }
+}
+// The inverse of one level (columns, then rows: waveletu16.go:213-257): the smooth subband from `ll` (the level below wrote it; the
+// coarsest level's lies in `a`), the detail subbands from `a`, the restored region to `dst` (a compact plane, or the 16-bit pixels).
+template <bool TO_U16>
+__global__ void __launch_bounds__(256) k_wv_inv2d(const int32_t *__restrict__ a, int stride, size_t fs, const int32_t *__restrict__ ll, int llstride, size_t llfs,
+                                                  void *__restrict__ dst_, int dstride, size_t dfs, int r, int c, int nf) {
+    // Mallat columns a tile's rows pass needs: smooth I0 .. I0 + WT_W, detail I0 - 1 .. I0 + WT_W; rows likewise
+    constexpr int CW = 2 * WT_W + 3, CH = 2 * WT_H + 3;
+    __shared__ int32_t s_q[CH][CW + 1];                                         // [smooth rows | detail rows] x [smooth cols | detail cols]
+    __shared__ int32_t s_c[2 * WT_H][CW + 1];                                   // after the columns pass: 2 WT_H restored rows of those columns
+    const int tid = (int)threadIdx.x;
+    const int nlc = (c + 1) / 2, nlr = (r + 1) / 2;
+    const int I0 = (int)blockIdx.x * WT_W, Y0 = (int)blockIdx.y * WT_H;
+    // local column lx <-> Mallat column: lx < WT_W + 1: smooth I0 + lx; else detail I0 - 1 + (lx - (WT_W + 1))
+    auto mcol = [&](int lx, bool &hi) { hi = lx > WT_W; return hi ? I0 - 1 + (lx - (WT_W + 1)) : I0 + lx; };
+    const bool in_x = I0 > 0 && 2 * (I0 + WT_W) + 1 < c, in_y = Y0 > 0 && 2 * (Y0 + WT_H) + 1 < r;   // (no boundary rule applies on that axis)
+    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z) {
+        for (int idx = tid; idx < CH * CW; idx += 256) {
+            const int ly = idx / CW, lx = idx - ly * CW;
+            bool hx, hy = ly > WT_H;
+            const int gx = mcol(lx, hx), gy = hy ? Y0 - 1 + (ly - (WT_H + 1)) : Y0 + ly;
+            int32_t v = 0;
+            const bool okx = gx >= 0 && (hx ? gx < c - nlc : gx < nlc), oky = gy >= 0 && (hy ? gy < r - nlr : gy < nlr);
+            if (okx && oky) {
+                if (!hx && !hy) v = ll[(size_t)f * llfs + (size_t)gy * llstride + gx];
+                else v = a[(size_t)f * fs + (size_t)((hy ? nlr : 0) + gy) * stride + (hx ? nlc : 0) + gx];
+            }
+            s_q[ly][lx] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < WT_H * CW; idx += 256) {                      // columns: pair lp of local column lx
+            const int lp = idx / CW, lx = idx - lp * CW, gp = Y0 + lp;
+            bool hx;
+            const int gx = mcol(lx, hx);
+            if (gp >= nlr || gx < 0 || (hx ? gx >= c - nlc : gx >= nlc)) continue;
+            if (in_y) {                                                         // smooth rows lp, lp + 1; detail rows gp - 1 .. gp + 1
+                const int32_t c0 = s_q[lp][lx], c1 = s_q[lp + 1][lx], dm = s_q[WT_H + 1 + lp][lx], d0 = s_q[WT_H + 2 + lp][lx], dp = s_q[WT_H + 3 + lp][lx];
+                const int32_t e0 = c0 - ((dm + d0 + 2) >> 2), e1 = c1 - ((d0 + dp + 2) >> 2);
+                s_c[2 * lp][lx] = e0; s_c[2 * lp + 1][lx] = d0 + ((e0 + e1) >> 1);
+                continue;
+            }
+            auto cf = [&](int j) { return j < nlr ? s_q[j - Y0][lx] : s_q[WT_H + 1 + (j - nlr) - (Y0 - 1)][lx]; };
+            int32_t ev, od; wv_pair(cf, r, gp, ev, od);
+            s_c[2 * lp][lx] = ev;
+            if (2 * gp + 1 < r) s_c[2 * lp + 1][lx] = od;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * WT_H * WT_W; idx += 256) {                // rows: pair li of local row ly
+            const int ly = idx / WT_W, li = idx - ly * WT_W, gy = 2 * Y0 + ly, gi = I0 + li;
+            if (gy >= r || gi >= nlc) continue;
+            int32_t ev, od;
+            if (in_x) {
+                const int32_t *q = &s_c[ly][0];
+                const int32_t dm = q[WT_W + 1 + li], d0 = q[WT_W + 2 + li], dp = q[WT_W + 3 + li];
+                ev = q[li] - ((dm + d0 + 2) >> 2);
+                od = d0 + ((ev + (q[li + 1] - ((d0 + dp + 2) >> 2))) >> 1);
+            } else {
+                auto cf = [&](int j) { return j < nlc ? s_c[ly][j - I0] : s_c[ly][WT_W + 1 + (j - nlc) - (I0 - 1)]; };
+                wv_pair(cf, c, gi, ev, od);
+            }
+            const size_t o = (size_t)f * dfs + (size_t)gy * dstride + 2 * gi;
+            if (TO_U16) {
+                typedef uint32_t wv_u32u __attribute__((aligned(2)));            // (a pixel pair in one store; rows of odd width start on odd pixels)
+                uint16_t *d = (uint16_t *)dst_ + o;
+                if (2 * gi + 1 < c) *(wv_u32u *)d = ((uint32_t)ev & 0xFFFFu) | ((uint32_t)od << 16); else d[0] = (uint16_t)ev;
+            } else {
+                typedef unsigned long long wv_u64u __attribute__((aligned(4)));
+                int32_t *d = (int32_t *)dst_ + o;
+                if (2 * gi + 1 < c) *(wv_u64u *)d = (uint32_t)ev | ((unsigned long long)(uint32_t)od << 32); else d[0] = ev;
             }
         }
-}
-template <bool TO_U16>
-__global__ void __launch_bounds__(256) k_wv_inv_rows(const int32_t *__restrict__ src, void *__restrict__ dst_, int r, int c, int stride, size_t fs, int nf) {
-    const int n_low = (c + 1) / 2, i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (i >= n_low) return;
-    for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z)
-        for (int y0 = (int)blockIdx.y * WV_RPB; y0 < r; y0 += (int)gridDim.y * WV_RPB)
-#pragma unroll 4
-            for (int y = y0; y < min(y0 + WV_RPB, r); y++) {
-                const size_t ro = (size_t)f * fs + (size_t)y * stride;
-                const int32_t *row = src + ro;
-                auto cf = [&](int j) { return row[j]; };
-                int32_t ev, od; wv_pair(cf, c, i, ev, od);
-                if (TO_U16) { uint16_t *o = (uint16_t *)dst_ + ro; o[2 * i] = (uint16_t)ev; if (2 * i + 1 < c) o[2 * i + 1] = (uint16_t)od; }
-                else { int32_t *o = (int32_t *)dst_ + ro; o[2 * i] = ev; if (2 * i + 1 < c) o[2 * i + 1] = od; }
-            }
+        __syncthreads();
+    }
 }
 // (a frame the transform leaves untouched: zero levels)
 __global__ void __launch_bounds__(256) k_wv_load(const uint16_t *px, int32_t *a, size_t n) {
@@ -709,7 +752,6 @@ __global__ void __launch_bounds__(1024) k_wv_scatter(MicUnit *units, int32_t *a,
 }
 
 int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
-dim3 lift_grid(int x, int y, int nf) { return dim3((unsigned)((x + 255) / 256), (unsigned)std::max(1, std::min(y, 32768)), (unsigned)std::min(nf, 4096)); }
 
 }  // namespace
 
@@ -730,19 +772,24 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     int rc;
     if ((rc = s->ensure(nf, 2 * n + 16))) return rc;                     // room for 3-word escapes
     DevBuf &a = s->wv_a, &b = s->wv_b;                                   // coefficient planes: kept by the session (no hipMalloc per call)
-    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
+    // b: the smooth planes between levels, two per frame (levels alternate), each (rows + 1) / 2 x (cols + 1) / 2 at most
+    const size_t ll_half = (size_t)((rows + 1) / 2) * (size_t)((cols + 1) / 2), ll_fs = 2 * ll_half;
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(ll_fs * 4 * (size_t)nf + 64))) return rc;
     auto done = [&](int code) { return code; };
     int32_t *A = (int32_t *)a.p, *B = (int32_t *)b.p;
     s->timer.reset(s->stream);
-    s->timer.mark("k_wv_fwd_rows+fwd_cols");
+    s->timer.mark("k_wv_fwd2d");
     if (applied == 0) hipLaunchKernelGGL(k_wv_load, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, d_src, A, n * (size_t)nf);
     { int r = rows, c = cols;
-      for (int l = 0; l < applied; l++) {
-          const dim3 gr = lift_grid((c + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), gc = lift_grid(c, ((r + 1) / 2 + WV_SP - 1) / WV_SP, nf);
-          if (l == 0) hipLaunchKernelGGL(k_wv_fwd_rows<true>, gr, dim3(256), 0, s->stream, (const void *)d_src, B, r, c, cols, n, nf);
-          else hipLaunchKernelGGL(k_wv_fwd_rows<false>, gr, dim3(256), 0, s->stream, (const void *)A, B, r, c, cols, n, nf);
-          hipLaunchKernelGGL(k_wv_fwd_cols, gc, dim3(256), 0, s->stream, (const int32_t *)B, A, r, c, cols, n, nf);
-          r = (r + 1) / 2; c = (c + 1) / 2;
+      for (int l = 0; l < applied; l++) {                                  // a level per launch: level l's smooth plane in B, parity l
+          const int rn = (r + 1) / 2, cn = (c + 1) / 2;
+          const dim3 g((unsigned)((cn + WT_W - 1) / WT_W), (unsigned)((rn + WT_H - 1) / WT_H), (unsigned)std::min(nf, 65535));
+          const bool last = l == applied - 1;
+          int32_t *lld = last ? A : B + ((l & 1) ? ll_half : 0);
+          const int lls = last ? cols : cn; const size_t llf = last ? n : ll_fs;
+          if (l == 0) hipLaunchKernelGGL(k_wv_fwd2d<true>, g, dim3(256), 0, s->stream, (const void *)d_src, cols, n, A, cols, n, lld, lls, llf, r, c, nf);
+          else hipLaunchKernelGGL(k_wv_fwd2d<false>, g, dim3(256), 0, s->stream, (const void *)(B + (((l - 1) & 1) ? ll_half : 0)), c, ll_fs, A, cols, n, lld, lls, llf, r, c, nf);
+          r = rn; c = cn;
       } }
     { const int arc = s->h_units.assign((size_t)nf, MicUnit{}); if (arc) return arc; }
     for (int i = 0; i < nf; i++) {
@@ -789,7 +836,8 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
         if (offs[(size_t)i + 1] < offs[(size_t)i] || offs[(size_t)i + 1] - offs[(size_t)i] > 0xFFFFFFF0ull) return MIC_ERR_ARGS;
     if ((rc = s->ensure(nf, 2 * n + 16))) return rc;
     DevBuf &a = s->wv_a, &b = s->wv_b;
-    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(n * 4 * (size_t)nf + 64))) return rc;
+    const size_t ll_half = (size_t)((rows + 1) / 2) * (size_t)((cols + 1) / 2), ll_fs = 2 * ll_half;   // (the smooth planes between levels, as in wv_compress_frames)
+    if ((rc = a.reserve(n * 4 * (size_t)nf + 64)) || (rc = b.reserve(ll_fs * 4 * (size_t)nf + 64))) return rc;
     auto done = [&](int code) { return code; };
     { const int arc = s->h_units.assign((size_t)nf, MicUnit{}); if (arc) return arc; }
     for (int i = 0; i < nf; i++) {
@@ -812,13 +860,16 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     s->timer.mark("k_wv_expand+coeffs (escape frames)");
     hipLaunchKernelGGL(k_wv_expand, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, -1, 1);
     hipLaunchKernelGGL(k_wv_coeffs, dim3((unsigned)nf), dim3(WV_THREADS), 0, s->stream, (MicUnit *)s->units.p, A, d);
-    s->timer.mark("k_wv_inv_cols+inv_rows");
+    s->timer.mark("k_wv_inv2d");
     if (levels == 0) hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];
-        hipLaunchKernelGGL(k_wv_inv_cols, lift_grid(cc, ((r + 1) / 2 + WV_SP - 1) / WV_SP, nf), dim3(256), 0, s->stream, (const int32_t *)A, B, r, cc, cols, n, nf);
-        if (l == 0) hipLaunchKernelGGL(k_wv_inv_rows<true>, lift_grid((cc + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)d_dst, r, cc, cols, n, nf);
-        else hipLaunchKernelGGL(k_wv_inv_rows<false>, lift_grid((cc + 1) / 2, (r + WV_RPB - 1) / WV_RPB, nf), dim3(256), 0, s->stream, (const int32_t *)B, (void *)A, r, cc, cols, n, nf);
+        const dim3 g((unsigned)(((cc + 1) / 2 + WT_W - 1) / WT_W), (unsigned)(((r + 1) / 2 + WT_H - 1) / WT_H), (unsigned)std::min(nf, 65535));
+        const bool coarsest = l == levels - 1;
+        const int32_t *lls = coarsest ? A : B + (((l + 1) & 1) ? ll_half : 0);
+        const int llst = coarsest ? cols : d.nc[l + 1]; const size_t llf = coarsest ? n : ll_fs;
+        if (l == 0) hipLaunchKernelGGL(k_wv_inv2d<true>, g, dim3(256), 0, s->stream, (const int32_t *)A, cols, n, lls, llst, llf, (void *)d_dst, cols, n, r, cc, nf);
+        else hipLaunchKernelGGL(k_wv_inv2d<false>, g, dim3(256), 0, s->stream, (const int32_t *)A, cols, n, lls, llst, llf, (void *)(B + ((l & 1) ? ll_half : 0)), cc, ll_fs, r, cc, nf);
     }
     s->timer.mark("end");
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
