@@ -11,6 +11,7 @@
 //     pinned already and is DMA-ed in place.
 // There is no CPU codec here: the host copies bytes and writes container headers.
 #include "mic_session.h"
+#include <chrono>
 
 #include <atomic>
 #include <deque>
@@ -109,7 +110,12 @@ private:
             PerDev &d = devs[(size_t)c.device];
             bool ok = hipSetDevice(c.device) == hipSuccess;
             if (ok && !d.ok) {
-                ok = hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking) == hipSuccess;
+                // a stream of the HIGHEST priority: the runtime keeps a hardware queue per priority level, and a transfer on an
+                // ordinary stream can land on the queue the session's kernels sit in and wait behind them (seen: the upload of
+                // sub-batch k + 1 and the download of k - 1 only made progress between two decodes)
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                ok = hipStreamCreateWithPriority(&d.st, hipStreamNonBlocking, hi) == hipSuccess;
                 for (int i = 0; ok && i < 2; i++)
                     ok = hipHostMalloc(&d.slot[i].pin, kChunk, hipHostMallocDefault) == hipSuccess &&
                          hipEventCreateWithFlags(&d.slot[i].ev, hipEventDisableTiming) == hipSuccess;
@@ -320,19 +326,27 @@ int decode_groups(mic_hip_session *s, std::vector<DecGroup> &G, std::vector<DecU
             if ((r = io_submit(sb.up, s->device, (uint8_t *)in[half]->p + q.dev, q.base + q.host_off, q.len, true))) return r;
         return MIC_OK;
     };
+    // MIC_HIP_TRACE=1: the stages of the pipeline with their wall times on stderr (tools/: where a call's time goes)
+    static const bool trace = getenv("MIC_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what, size_t k) {
+        if (trace) fprintf(stderr, "[mic_hip decode] %7.2f ms  %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what, k);
+    };
     if ((rc = upload(*subs[0], 0))) { (void)subs[0]->up.wait(); return rc; }
     for (size_t k = 0; k < subs.size() && rc == MIC_OK; k++) {
         Sub &sb = *subs[k];
         const int half = (int)(k & 1);
         rc = sb.up.wait();
+        mark("streams on the device", k);
         // this sub-batch decodes into the pixel half that sub-batch k - 2 is (was) being downloaded from
-        if (k >= 2) { const int r2 = subs[k - 2]->down.wait(); if (rc == MIC_OK) rc = r2; }
+        if (k >= 2) { const int r2 = subs[k - 2]->down.wait(); if (rc == MIC_OK) rc = r2; mark("pixels of sub-batch on the host", k - 2); }
         if (rc == MIC_OK && k + 1 < subs.size()) rc = upload(*subs[k + 1], half ^ 1);
         if (rc == MIC_OK) rc = outb[half]->reserve(sb.px * 2 + 64);
         const int nb = sb.i1 - sb.i0;
         std::vector<int32_t> st((size_t)nb);
         if (rc == MIC_OK) rc = session_decode_enqueue_spans(s, (const uint8_t *)in[half]->p, sb.begins.data(), sb.ends.data(), sb.units.data(), nb, (uint16_t *)outb[half]->p);
         if (rc == MIC_OK) rc = session_decode_finish(s, st.data());
+        mark("decoded", k);
         if (rc != MIC_OK) break;
         for (int i = sb.i0; i < sb.i1;) {
             DecGroup &g = G[(size_t)U[(size_t)i].group];
@@ -356,6 +370,7 @@ int decode_groups(mic_hip_session *s, std::vector<DecGroup> &G, std::vector<DecU
         }
     }
     for (auto &sb : subs) { const int r2 = sb->up.wait(); const int r3 = sb->down.wait(); if (rc == MIC_OK) rc = r2 ? r2 : r3; }
+    mark("all pixels on the host", subs.size());
     return rc;
 }
 
