@@ -203,17 +203,23 @@ int next_cut(const std::vector<U> &units, int i0, size_t target) {
     }
     return i1;
 }
-inline size_t pipeline_target(size_t n_units) {
-    // two or three sub-batches of >= 1152 units; smaller calls go as one
-    if (n_units < 2304) return n_units ? n_units : 1;
-    const size_t parts = std::min<size_t>(3, n_units / 1152);
+// Sub-batches of a call: the transfers of one overlap the kernels of its neighbours.  Measured on 2304 strips, pinned buffers, parts
+// 2 / 3 / 4 / 6: encode 87 / 83 / 88 / 90 ms, decode 95 / 98 / 107 / 132 ms.  A decode costs the tANS chain's ~17 ms whatever its size
+// (one serial chain per stream), so decode cuts into parts of >= 1152 units; encode kernels scale with their units (7 ms for 2304),
+// but upload and download do not run at full rate side by side on this box (the call stays at bytes in / H2D + bytes out / D2H), so
+// finer cuts only add launches: parts of >= 768 units, three at most either way.
+inline size_t pipeline_target(size_t n_units, bool encode) {
+    const size_t min_units = encode ? 768 : 1152, max_parts = 3;
+    static const char *ov = getenv("MIC_HIP_PIPELINE_PARTS");              // (experiments: force the number of parts)
+    size_t parts = ov ? (size_t)std::max(1, atoi(ov)) : std::min(max_parts, n_units / min_units);
+    if (parts < 2) return n_units ? n_units : 1;
     return (n_units + parts - 1) / parts;
 }
 
 int encode_groups(mic_hip_session *s, std::vector<EncGroup> &G, std::vector<EncUnit> &U) {
     const int n = (int)U.size();
     if (n == 0) return MIC_OK;
-    const size_t target = pipeline_target((size_t)n);
+    const size_t target = pipeline_target((size_t)n, true);
     struct Sub { int i0, i1; IoReq up, down; std::vector<mic_hip_unit> units; size_t px = 0; };
     std::vector<std::unique_ptr<Sub>> subs;
     for (int i0 = 0; i0 < n;) { auto sb = std::make_unique<Sub>(); sb->i0 = i0; sb->i1 = next_cut(U, i0, target); i0 = sb->i1; subs.push_back(std::move(sb)); }
@@ -287,7 +293,7 @@ int encode_groups(mic_hip_session *s, std::vector<EncGroup> &G, std::vector<EncU
 int decode_groups(mic_hip_session *s, std::vector<DecGroup> &G, std::vector<DecUnit> &U) {
     const int n = (int)U.size();
     if (n == 0) return MIC_OK;
-    const size_t target = pipeline_target((size_t)n);
+    const size_t target = pipeline_target((size_t)n, false);
     struct Sub { int i0, i1; IoReq up, down; std::vector<mic_hip_unit> units; std::vector<uint64_t> begins, ends; size_t px = 0; };
     std::vector<std::unique_ptr<Sub>> subs;
     for (int i0 = 0; i0 < n;) { auto sb = std::make_unique<Sub>(); sb->i0 = i0; sb->i1 = next_cut(U, i0, target); i0 = sb->i1; subs.push_back(std::move(sb)); }
