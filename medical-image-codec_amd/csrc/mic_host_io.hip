@@ -58,15 +58,16 @@ class IoPool {
 public:
     static IoPool &get() { static IoPool p; return p; }
     void push(const IoChunk &c) {
-        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(c); }
-        cv_.notify_one();
+        { std::lock_guard<std::mutex> lk(mu_); q_[c.to_device ? 0 : 1].push_back(c); }
+        cv_.notify_all();
     }
     int threads() const { return (int)th_.size(); }
 private:
     struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; bool busy = false; IoReq *req = nullptr; void *host_dst = nullptr; size_t bytes = 0; };
     struct PerDev { hipStream_t st = nullptr; Slot slot[2]; int next = 0; bool ok = false; };
     std::vector<std::thread> th_;
-    std::deque<IoChunk> q_;
+    std::deque<IoChunk> q_[2];                     // uploads, downloads: half the workers look at one first, half at the other, so a
+                                                   // download queued behind a long upload starts at once and the link runs both ways
     std::mutex mu_; std::condition_variable cv_;
     bool stop_ = false;
 
@@ -75,7 +76,7 @@ private:
         int n = e ? atoi(e) : 0;
         if (n <= 0) n = (int)std::min<unsigned>(8u, std::max<unsigned>(2u, std::thread::hardware_concurrency() / 2));
         n = std::min(n, 32);
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); });
+        for (int i = 0; i < n; i++) th_.emplace_back([this, i] { run(i & 1); });
     }
     ~IoPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -89,7 +90,7 @@ private:
         s.busy = false;
         s.req->done(ok);
     }
-    void run() {
+    void run(int first) {
         std::vector<PerDev> devs;
         for (;;) {
             IoChunk c;
@@ -98,8 +99,10 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 bool inflight = false;
                 for (auto &d : devs) inflight |= d.slot[0].busy || d.slot[1].busy;
-                if (q_.empty() && !inflight && !stop_) cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-                if (!q_.empty()) { c = q_.front(); q_.pop_front(); have = true; }
+                auto none = [&] { return q_[0].empty() && q_[1].empty(); };
+                if (none() && !inflight && !stop_) cv_.wait(lk, [&] { return stop_ || !none(); });
+                std::deque<IoChunk> &q = !q_[first].empty() ? q_[first] : q_[first ^ 1];
+                if (!q.empty()) { c = q.front(); q.pop_front(); have = true; }
                 else if (stop_ && !inflight) return;
             }
             if (!have) {                                   // nothing new: finish what is in flight
@@ -203,11 +206,10 @@ int next_cut(const std::vector<U> &units, int i0, size_t target) {
     }
     return i1;
 }
-// Sub-batches of a call: the transfers of one overlap the kernels of its neighbours.  Measured on 2304 strips, pinned buffers, parts
-// 2 / 3 / 4 / 6: encode 87 / 83 / 88 / 90 ms, decode 95 / 98 / 107 / 132 ms.  A decode costs the tANS chain's ~17 ms whatever its size
-// (one serial chain per stream), so decode cuts into parts of >= 1152 units; encode kernels scale with their units (7 ms for 2304),
-// but upload and download do not run at full rate side by side on this box (the call stays at bytes in / H2D + bytes out / D2H), so
-// finer cuts only add launches: parts of >= 768 units, three at most either way.
+// Sub-batches of a call: the transfers of one overlap the kernels of its neighbours.  A decode costs the tANS chain's ~17 ms whatever
+// its size (one serial chain per stream), so decode cuts into parts of >= 1152 units; encode kernels scale with their units (7 ms
+// for 2304), so encode cuts into parts of >= 768 -- three at most either way: measured on 2304 strips in pinned buffers, encode /
+// decode with 2 parts 75 / 92 ms (decode's default), 3 parts 78 / 94 (encode's default: 75 with decode at 2), 4 parts 88 / 106.
 inline size_t pipeline_target(size_t n_units, bool encode) {
     const size_t min_units = encode ? 768 : 1152, max_parts = 3;
     static const char *ov = getenv("MIC_HIP_PIPELINE_PARTS");              // (experiments: force the number of parts)
