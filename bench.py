@@ -436,6 +436,9 @@ def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
              "encode_ms": round(best[0] * 1e3, 2), "decode_ms": round(best[1] * 1e3, 2),
              "pcie_floor_ms": {"encode": round(floor_enc * 1e3, 2), "decode": round(floor_dec * 1e3, 2)},
              "fraction_of_pcie_floor": {"encode": round(floor_enc / best[0], 3), "decode": round(floor_dec / best[1], 3)},
+             # (the floor above moves one way at a time; the link is full duplex, so a pipelined call can beat it.  Both ways at once:)
+             "pcie_duplex_floor_ms": {"encode": round(max(raw / rates["h2d"], comp / rates["d2h"]) / 1e6, 2),
+                                      "decode": round(max(comp / rates["h2d"], raw / rates["d2h"]) / 1e6, 2)},
              "b1_encode_ms": round((t1 - t0) * 1e3, 2), "b1_decode_ms": round((t2 - t1) * 1e3, 2)}
         if kind == "pinned":
             for a in (src, cbuf, back):
