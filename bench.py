@@ -469,6 +469,12 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) figure")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the result.  Native libraries write there too (RCCL prints a version banner when a process group comes
+    # up): while the bench runs, file descriptor 1 points at stderr; it is put back for the line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -669,8 +675,11 @@ def main():
         out["crossover_frames"] = cross
     if dist is not None:
         dist.barrier()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                                                        # (whatever the teardown prints is not the result)
     if dist is not None:
         dist.destroy_process_group()
 
