@@ -299,10 +299,11 @@ def _piecewise_rows(synth, w, h, seed, alphabet, maxseg):
     return out[: w * h].reshape(h, w)
 
 
-@pytest.mark.parametrize("maxv", [15, 31, 255, 1023])
+@pytest.mark.parametrize("maxv", [15, 31, 63, 127, 255, 1023])
 def test_tokeniser_fuzz_small_depths(mic, mico, synth, gpu_ready, maxv):
-    """Small depths make midCount tiny (7, 15, 127, 511): same-run and literal chunking
-    (rlecompressu16.go:57-67) fire constantly, including at the end of the stream."""
+    """Small depths make midCount tiny (7, 15, 31, 63, 127, 511): same-run and literal chunking
+    (rlecompressu16.go:57-67) fire constantly, including at the end of the stream.  63 and 127 (chunks of 28 and 60) are the shortest
+    the closed-form count / position-per-lane write of the tokeniser takes: a count wraps in most threads there."""
     frames, want = [], []
     for k in range(24):
         w, h = 97 + 13 * k, 40 + (k % 5) * 9
