@@ -125,3 +125,23 @@ def test_fse_stage_is_the_same_stream_call_after_call(mic, mico, synth, gpu_read
         assert rc == 0
         for _ in range(4):
             assert mic.fse_compress_u16(t, flavour) == want, n
+
+
+def test_large_two_state_unit_whose_first_attempt_fails_takes_the_fallback_chain(mic, mico, synth, gpu_ready):
+    """The 512-thread tANS encoder keeps the two-state walk in a kernel of its own; a unit whose two-state attempt gives up (here:
+    12-bit noise, no gain) is handed to the instance that holds the other walks and starts its N -> ... -> 1 chain over there
+    (multiframecompress.go:15-93).  Whatever the oracle says -- a stream of fewer states or an error code -- the GPU must say too."""
+    noise = (synth.hash_u64(700 * 300, 5) & np.uint64(0xFFF)).astype(np.uint16).reshape(300, 700)
+    smooth = synth.xr_like(cols=700, rows=300, depth=12, seed=4)
+    mixed = np.where((np.arange(700)[None, :] // 50) % 2 == 0, noise, smooth).astype(np.uint16)
+    for img in (noise, mixed):
+        for ns in (2, 4, 8):
+            rc, want = mico.compress_single_frame(img, 4095, ns)
+            if rc == 0:
+                got = mic.compress_single_frame(img, 700, 300, 4095, ns)
+                assert got == want
+                assert np.array_equal(mic.decompress_single_frame(got, 700, 300), img)
+            else:
+                with pytest.raises(mic.MicError) as e:
+                    mic.compress_single_frame(img, 700, 300, 4095, ns)
+                assert e.value.code == rc
