@@ -127,21 +127,27 @@ def test_fse_stage_is_the_same_stream_call_after_call(mic, mico, synth, gpu_read
             assert mic.fse_compress_u16(t, flavour) == want, n
 
 
-def test_large_two_state_unit_whose_first_attempt_fails_takes_the_fallback_chain(mic, mico, synth, gpu_ready):
-    """The 512-thread tANS encoder keeps the two-state walk in a kernel of its own; a unit whose two-state attempt gives up (here:
-    12-bit noise, no gain) is handed to the instance that holds the other walks and starts its N -> ... -> 1 chain over there
-    (multiframecompress.go:15-93).  Whatever the oracle says -- a stream of fewer states or an error code -- the GPU must say too."""
+def test_large_noisy_units_through_the_two_state_instance(mic, mico, synth, gpu_ready):
+    """The 512-thread tANS encoder keeps the two-state walk in a kernel of its own; a unit whose two-state attempt gives up would be
+    handed to the instance that holds the other walks and start its N -> ... -> 1 chain over there (multiframecompress.go:15-93).
+    At tableLog <= 13 a token costs at most 13 bits, so "no gain" needs a header as large as the payload's slack: a scan of 12-bit
+    noise frames from 64 x 48 to 256 x 192 found none (below ~150 x 110 the table build already fails, above it two states code) --
+    the hand-over is there for completeness; this test pins the noisy large units on either side of it.  Whatever the oracle says
+    -- a stream or an error code -- the GPU must say too."""
     noise = (synth.hash_u64(700 * 300, 5) & np.uint64(0xFFF)).astype(np.uint16).reshape(300, 700)
     smooth = synth.xr_like(cols=700, rows=300, depth=12, seed=4)
     mixed = np.where((np.arange(700)[None, :] // 50) % 2 == 0, noise, smooth).astype(np.uint16)
-    for img in (noise, mixed):
+    small = (synth.hash_u64(140 * 100, 5) & np.uint64(0xFFF)).astype(np.uint16).reshape(100, 140)      # (the table build fails: -8)
+    edge = (synth.hash_u64(160 * 120, 5) & np.uint64(0xFFF)).astype(np.uint16).reshape(120, 160)       # (the first size that codes)
+    for img in (noise, mixed, small, edge):
+        h, w = img.shape
         for ns in (2, 4, 8):
             rc, want = mico.compress_single_frame(img, 4095, ns)
             if rc == 0:
-                got = mic.compress_single_frame(img, 700, 300, 4095, ns)
+                got = mic.compress_single_frame(img, w, h, 4095, ns)
                 assert got == want
-                assert np.array_equal(mic.decompress_single_frame(got, 700, 300), img)
+                assert np.array_equal(mic.decompress_single_frame(got, w, h), img)
             else:
                 with pytest.raises(mic.MicError) as e:
-                    mic.compress_single_frame(img, 700, 300, 4095, ns)
+                    mic.compress_single_frame(img, w, h, 4095, ns)
                 assert e.value.code == rc
