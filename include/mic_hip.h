@@ -131,7 +131,9 @@ typedef struct mic_hip_dec_job {
 /* Return value: MIC_OK when the batch ran (inspect per-job status), or a global error.
  * Host buffers are ordinary (pageable) memory or pinned memory (below); large batches run as a pipeline of sub-batches --
  * upload, kernels and download of neighbouring sub-batches overlap -- and concurrent callers run on different sessions of a
- * small pool (MIC_HIP_POOL sessions, default 3), as the reference's C codec runs concurrent goroutines (ojph/mic_parallel.h:47-48). */
+ * small pool (MIC_HIP_POOL sessions, default 3), as the reference's C codec runs concurrent goroutines (ojph/mic_parallel.h:47-48).
+ * Environment, read once: MIC_HIP_WS_BUDGET_MB (device memory a default session may grow to), MIC_HIP_PIPELINE_PARTS (force the
+ * number of sub-batches), MIC_HIP_TRACE=1 (the pipeline's stages with wall times on stderr). */
 int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs);
 int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs);
 
