@@ -77,7 +77,7 @@ int DefaultLease::acquire() {
     tl_default = s; tl_depth = 1; held = true;
     int rc = s->activate();
     if (rc) return rc;
-    if (!s->stream) HIP_TRY(hipStreamCreate(&s->stream));
+    if (!s->stream) HIP_TRY(mic_stream_create(&s->stream));
     return MIC_OK;
 }
 DefaultLease::~DefaultLease() {

@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/mic_hip.h"
@@ -31,6 +32,18 @@ extern std::mutex g_mu;     // guards the device choice and the pool of default 
 extern int g_device;
 int ensure_device();
 int check_device(int device);      // MIC_OK when `device` exists and is gfx950 (cached per device)
+
+// A session's stream.  MIC_HIP_SESSION_PRIO_CYCLE=1 (experiments): successive sessions get successive priority levels, i.e.
+// hardware queues of their own -- the runtime keeps a queue per level, and streams of one level may share one.
+inline hipError_t mic_stream_create(hipStream_t *st) {
+    static const bool cycle = getenv("MIC_HIP_SESSION_PRIO_CYCLE") != nullptr;
+    if (!cycle) return hipStreamCreate(st);
+    static std::atomic<int> next{0};
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                       // (lo is the numerically larger, least urgent one)
+    const int span = lo - hi + 1, k = next.fetch_add(1) % (span > 0 ? span : 1);
+    return hipStreamCreateWithPriority(st, hipStreamDefault, lo - k);
+}
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -142,7 +155,7 @@ struct mic_hip_session {
 
     size_t tab_syms = kSym;                  // symbols / states the table slabs of the current layout hold per unit
     int ensure(int n, size_t px, int want_tier = 2) {
-        if (!stream) HIP_TRY(hipStreamCreate(&stream));
+        if (!stream) HIP_TRY(mic_stream_create(&stream));
         // The workspace takes the shape of the current call (n units of up to px pixels, in the tier asked for); buffers only ever
         // grow.  Sizing for max(n) x max(px) over a session's history would ask for the bounding box of unrelated calls (one
         // 4-megapixel wavelet frame, then 3000 WSI planes of 256 x 256).
