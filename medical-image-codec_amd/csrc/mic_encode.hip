@@ -781,6 +781,9 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_THREADS 512              // two groups per CU (128 VGPRs each): the fix-up stalls of one overlap the other's work
 #define TE_WAVES 8
 #define TE_BLK 64                 // the largest block a walk reads at a time, in tokens (te_encode: BLK)
+#ifndef TE_WARM_TOK
+#define TE_WARM_TOK 128           // tokens of the predecessor's range a thread walks first (a multiple of 64)
+#endif
 #ifndef TE_NARROW_WPS
 #define TE_NARROW_WPS 6          // waves per SIMD the two-state instance is compiled for (6: three groups per CU; it needs 64 registers)
 #endif
@@ -825,7 +828,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     // tokens per block: the two-state walk (the usual flavour) reads a whole 128-byte line at a time (two 64-byte halves read apart were two
     // fetches: the line does not survive in a cache between them); the wider walks have no registers for that
     constexpr int BLK = (N == 2 && !RANS && TTL) ? TE_BLK2 : 32;
-    constexpr uint32_t RGRP = 128 / BLK, WARM = 384 / BLK;   // blocks per fix-up record (128 tokens); blocks of the predecessor's range walked as warm-up
+    constexpr uint32_t RGRP = 128 / BLK, WARM = TE_WARM_TOK / BLK;   // blocks per fix-up record (128 tokens); blocks of the predecessor's range walked as warm-up
     typedef TeBlkT<BLK> TeBlk;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = u.ntok, tl = u.table_log, size = 1u << tl;
