@@ -287,22 +287,29 @@ __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *nor
     int32_t threshold = (int32_t)(1u << nb_bits);
     int32_t got_total = 0;
     nb_bits++;
-    if (dw && iend >= 24) {
-        uint64_t P = 4;                                                   // bit position, relative to b
-        const uint64_t lim = ((uint64_t)iend - 16) * 8;                   // an iteration starts (and a zero-run skip lands) at P <= lim only
+    if (dw && iend >= 24 && iend < (1 << 27)) {                            // (an LDS stage: bit positions fit 32 bits -- half the instructions of 64-bit ones)
+        uint32_t P = 4;                                                   // bit position, relative to b
+        const uint32_t lim = ((uint32_t)iend - 16) * 8;                   // an iteration starts (and a zero-run skip lands) at P <= lim only
         uint32_t wi = 0xFFFFFFFEu; uint64_t W = 0;                        // window: dwords wi, wi + 1 (none yet)
-        auto snap = [&](uint64_t p) -> uint32_t {
-            const uint64_t pa = p + 8ull * boff;
-            const uint32_t i = (uint32_t)(pa >> 5);
+        auto snap = [&](uint32_t p) -> uint32_t {
+            const uint32_t pa = p + 8u * boff;
+            const uint32_t i = pa >> 5;
             if (i != wi) {
                 if (i == wi + 1) W = (W >> 32) | ((uint64_t)dw[i + 1] << 32);
                 else W = (uint64_t)dw[i] | ((uint64_t)dw[i + 1] << 32);
                 wi = i;
             }
-            return (uint32_t)(W >> ((uint32_t)pa & 31u));
+            return (uint32_t)(W >> (pa & 31u));
         };
+        // The loop is written for the scalar unit it runs on (one lane's uniform work is scalarised by the compiler): a TAKEN branch
+        // costs it tens of cycles, and the first form -- early returns inside nested ifs -- compiled to a dozen of them per symbol
+        // (550 cycles a symbol: the parse was 0.95 ms of a 33 ms step).  Selects instead of branches, one exit, errors in `fail`.
+        int fail = 0;
+        // (with the LDS stage the counts are in HBM: stores through a global-address-space pointer -- a FLAT store also counts on
+        // lgkmcnt, and the window refill's wait for its LDS read would wait for the store in front of it too)
+        const mic_gp<NormT> gnorm = mic_g(norm);
         while (remaining > 1 && P <= lim) {
-            const uint64_t P0 = P;
+            const uint32_t P0 = P;
             uint32_t bs = snap(P);
             if (previous0) {
                 uint32_t n0 = charnum;
@@ -311,38 +318,41 @@ __device__ inline int mic_read_ncount(const uint8_t *b, uint32_t len, NormT *nor
                     n0 += 24; P += 16;
                     if (P > lim) { bail = true; break; }
                     bs = snap(P);
-                    if (n0 > MIC_MAXSYM + 24) return MICD_ERR_CORRUPT;
+                    if (n0 > MIC_MAXSYM + 24) { fail = MICD_ERR_CORRUPT; break; }
                 }
+                if (fail) break;
                 if (bail) { P = P0; break; }                              // (this iteration again, byte-wise)
                 while ((bs & 3) == 3) { n0 += 3; bs >>= 2; P += 2; }
                 n0 += bs & 3; P += 2;
-                if (n0 > MIC_MAXSYM) return MICD_ERR_CORRUPT;
-                if (n0 > norm_cap) return MICD_ERR_UNSUPPORTED;
+                if (n0 > MIC_MAXSYM || n0 > norm_cap) { fail = n0 > MIC_MAXSYM ? MICD_ERR_CORRUPT : MICD_ERR_UNSUPPORTED; break; }
                 if (PREZEROED) charnum = max(charnum, n0);
-                else while (charnum < n0) { norm[charnum & 0xffff] = 0; charnum++; }
+                else while (charnum < n0) { gnorm[charnum & 0xffff] = 0; charnum++; }
                 bs = snap(P);
             }
             const int32_t max = (2 * threshold - 1) - remaining;
-            int32_t count;
-            if (((int32_t)bs & (threshold - 1)) < max) { count = (int32_t)bs & (threshold - 1); P += nb_bits - 1; }
-            else {
-                count = (int32_t)bs & (2 * threshold - 1);
-                if (count >= threshold) count -= max;
-                P += nb_bits;
-            }
+            const int32_t lowv = (int32_t)bs & (threshold - 1), fullv = (int32_t)bs & (2 * threshold - 1);
+            const bool shortf = lowv < max;                               // the field is one bit shorter
+            int32_t count = shortf ? lowv : (fullv >= threshold ? fullv - max : fullv);
+            P += shortf ? nb_bits - 1 : nb_bits;
             count--;
-            if (count < 0) { remaining += count; got_total -= count; }
-            else { remaining -= count; got_total += count; }
-            if (charnum > MIC_MAXSYM) return MICD_ERR_CORRUPT;
-            if (charnum >= norm_cap) return MICD_ERR_UNSUPPORTED;
-            norm[charnum & 0xffff] = (NormT)count;
+            const int32_t ac = count < 0 ? -count : count;               // (count = -1 is a symbol of probability "less than one": it takes one slot)
+            remaining -= ac; got_total += ac;
+            if (charnum > MIC_MAXSYM || charnum >= norm_cap) { fail = charnum > MIC_MAXSYM ? MICD_ERR_CORRUPT : MICD_ERR_UNSUPPORTED; break; }
+            gnorm[charnum & 0xffff] = (NormT)count;
             charnum++;
             previous0 = (count == 0);
-            while (remaining < threshold) {
-                nb_bits--; threshold >>= 1;
-                if (threshold == 0) break;
+            if (remaining < threshold) {
+                if (remaining >= 1) {                                     // threshold = the power of two at or below `remaining`, nbBits with it
+                    const int32_t k = 31 - (int32_t)__builtin_clz((uint32_t)remaining);
+                    nb_bits -= (uint32_t)((31 - (int32_t)__builtin_clz((uint32_t)threshold)) - k);
+                    threshold = 1 << k;
+                } else while (remaining < threshold) {                    // (a damaged header: the reference's loop as it stands)
+                    nb_bits--; threshold >>= 1;
+                    if (threshold == 0) break;
+                }
             }
         }
+        if (fail) return fail;
         off = (int64_t)(P >> 3); bit_count = (uint32_t)P & 7u;            // the canonical state of the byte-wise reader
         bit_stream = mic_rd_u32(b, len, off, &err) >> bit_count;
         if (err) return MICD_ERR_CORRUPT;
