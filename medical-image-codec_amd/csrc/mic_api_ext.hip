@@ -402,7 +402,6 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
     for (const Level &l : lv) total_tiles += (size_t)l.tx * l.ty;
     const size_t hdr = 48 + 20 * (size_t)nlev + 16 * total_tiles;
     if (out_cap < hdr) return MIC_ERR_CAPACITY;
-    const size_t npx = (size_t)tile_w * tile_h;
     // pyramid on the device
     std::vector<DevBuf> img((size_t)nlev);
     auto cleanup = [&]() { for (auto &b : img) b.release(); };

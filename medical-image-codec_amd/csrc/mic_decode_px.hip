@@ -914,7 +914,6 @@ __global__ void __launch_bounds__(64) k_dec_predict_grad(MicUnit *units, int w_l
             return g;
         };
         uint32_t left = 0;                                       // W of the next pixel
-        uint32_t top[PG_Q] = { 0u, 0u, 0u, 0u };                 // the row above at this step's columns (set below)
         uint32_t nw = 0;                                         // ... and at the column before them
         uint32_t mine[PG_Q] = { 0u, 0u, 0u, 0u };                // this lane's previous result
         Grp nx = fetch(-(int)lane);
