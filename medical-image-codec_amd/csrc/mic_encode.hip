@@ -822,12 +822,28 @@ __device__ __forceinline__ void te_set(TeBlkT<B> &b, int j, uint32_t x) {
 // tokens are walked together (N independent LDS look-ups in flight), 64 bytes per memory access.
 // TTL: the per-symbol records (symbolTT / rANS freq+bias) were copied to LDS (alphabets up to TE_TT_SYMS);
 // otherwise every coding step gathers them from HBM.
+#if defined(TE_INLINE)
+#define TE_FN_ATTR __forceinline__
+#elif defined(TE_NOINLINE)
+#define TE_FN_ATTR __noinline__
+#else
+#define TE_FN_ATTR
+#endif
+#ifdef TE_BAR_VM        // diagnostic: every barrier of the walk also waits for the group's outstanding global memory operations
+#define TE_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#else
+#define TE_SYNC() __syncthreads()
+#endif
 template <int N, bool RANS, bool TTL, int T, bool FS>   // FS: the LDS state table holds whole states (they fit 16 bits up to tableLog 15)
-__device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
+__device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                           uint16_t *s_E, uint32_t *s_scan, int &rc_out, uint32_t &total_bytes_out) {   // s_E: T x N end states
     // tokens per block: the two-state walk (the usual flavour) reads a whole 128-byte line at a time (two 64-byte halves read apart were two
     // fetches: the line does not survive in a cache between them); the wider walks have no registers for that
+#ifdef TE_BLK1_64   // diagnostic: the one-state walk on whole lines too (the state of the code when round 3 saw the differences)
+    constexpr int BLK = (N <= 2 && !RANS && TTL) ? TE_BLK2 : 32;
+#else
     constexpr int BLK = (N == 2 && !RANS && TTL) ? TE_BLK2 : 32;
+#endif
     constexpr uint32_t RGRP = 128 / BLK, WARM = TE_WARM_TOK / BLK;   // blocks per fix-up record (128 tokens); blocks of the predecessor's range walked as warm-up
     typedef TeBlkT<BLK> TeBlk;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -940,7 +956,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
     MIC_STAMP_AT(u, 8);
     // ---- 2. fix-up rounds to the fixed point -----------------------------------------------------
     for (uint32_t round = 0; round < T; round++) {
-        __syncthreads();
+        TE_SYNC();
         int changed = 0;
         uint32_t e_out[N], st2[N]; bool any = false;
 #pragma unroll
@@ -974,7 +990,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                 for (int k = 0; k < N; k++) if (st2[k] != e_out[k]) { e_out[k] = st2[k]; changed = 1; }
             }
         }
-        __syncthreads();                                   // every thread has read its predecessor's states
+        TE_SYNC();                                   // every thread has read its predecessor's states
 #pragma unroll
         for (int k = 0; k < N; k++) s_E[(tid) * N + k] = (uint16_t)(e_out[k] - size);
 #ifdef MIC_STAMP
@@ -982,7 +998,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
 #endif
         if (!__syncthreads_or(changed)) break;
     }
-    __syncthreads();
+    TE_SYNC();
     // empty tail threads may not have been reached by a round: propagate the final states down
     // (thread T-1 must hold the end states of every chain for the trailer)
     if (tid == 0) {
@@ -991,12 +1007,19 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         for (int k = 0; k < N; k++) s_E[(T - 1) * N + k] = s_E[(last) * N + k];
     }
     __threadfence_block();
-    __syncthreads();
+    TE_SYNC();
+#ifdef TE_CHECK     // diagnostic: the walk's invariants, reported through u.dbg[15] (the kernel turns it into a status)
+    {
+        const uint32_t lastown_c = (nblk + per - 1) / per; uint32_t bad = 0;
+        if (tid > 0 && tid < lastown_c) for (int k = 0; k < N; k++) if (assumed[k] != (uint32_t)s_E[(tid - 1) * N + k] + size) bad |= 1u;
+        if (bad) { atomicOr(&u.dbg[15], bad); atomicMin(&u.dbg[14], tid | 0x10000u); }
+    }
+#endif
     MIC_STAMP_AT(u, 9);
     // ---- 3. bit offsets ---------------------------------------------------------------------------
     const uint32_t incl = tk_wave_incl_add(mybits, lane);
     if (lane == 63) s_scan[wave] = incl;
-    __syncthreads();
+    TE_SYNC();
     uint32_t woff = 0, sym_bits = 0;
 #pragma unroll
     for (int wv = 0; wv < (T / 64); wv++) { const uint32_t v = s_scan[wv]; if ((uint32_t)wv < wave) woff += v; sym_bits += v; }
@@ -1023,7 +1046,7 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         else if ((uint64_t)hdr_len + total_bytes >= (uint64_t)n * 2) rc0 = MICD_ERR_INCOMPRESSIBLE;   // fse2state.go:58-60
         s_scan[(T / 64)] = (uint32_t)rc0; s_scan[(T / 64) + 1] = total_bytes;
     }
-    __syncthreads();
+    TE_SYNC();
     const int rc = (int)s_scan[(T / 64)];
     total_bytes_out = s_scan[(T / 64) + 1];
     rc_out = rc;
@@ -1052,6 +1075,9 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
         } else { pend = v; have_pend = true; }
         q++;
     };
+#ifdef TE_CHECK
+    uint32_t pbits = 0;
+#endif
     {
         uint32_t stp[N];
         const uint32_t lastown = (nblk + per - 1) / per;   // threads 0 .. lastown-1 own tokens; s_E[T-1] was overwritten for the trailer
@@ -1079,6 +1105,9 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                         f4 += nb;
                     }
                 }
+#ifdef TE_CHECK
+                pbits += f4;
+#endif
                 acc |= t4 << filled;                                             // filled < 64
                 const uint32_t nf = filled + f4;
                 if (nf >= 64) {
@@ -1088,26 +1117,46 @@ __device__ void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *s_tt,
                 } else filled = nf;
             }
         }
+#ifdef TE_CHECK
+        {
+            uint32_t bad = pbits != mybits ? 2u : 0u;
+            if (tid < lastown && tid != T - 1) for (int k = 0; k < N; k++) if (stp[k] != (uint32_t)s_E[tid * N + k] + size) bad |= 4u;
+            if (bad) { atomicOr(&u.dbg[15], bad); atomicMin(&u.dbg[13], tid | 0x10000u); }
+        }
+#endif
     }
     if (mybits > 0 && filled > 0) emit(acc);                             // the thread's last, partial unit
     if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
+#ifdef TE_NO_HANDOFF    // diagnostic: the barrier round 3 had here before MIC_GROUP_HANDOFF
+    __threadfence_block(); __syncthreads();
+#else
     MIC_GROUP_HANDOFF();                                   // (every unit is in L2 before anything is OR-ed into it)
+#endif
     if (have_lead && lead_val) (void)__hip_atomic_fetch_or(&words64[first_q], (unsigned long long)lead_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_block();
-    __syncthreads();
+    TE_SYNC();
     if (tid == 0) {
-        // final states, last lane first (fse2state.go:194-197), then the end mark
+        // final states, last lane first (fse2state.go:194-197), then the end mark.  The word the symbols' last bit lies in is shared
+        // with the atomic ORs other threads have just made (executed at L2, nothing here waits for them): the trailer ORs its bits in
+        // the same way instead of reading the word back; the words wholly behind that bit are zeroed first and the zeroes are
+        // acknowledged before the first OR.
         uint64_t pos = 8ull * lead + sym_bits;
         const uint64_t end = pos + (uint64_t)N * tl + 1;
         for (uint64_t ww = (pos + 31) >> 5; ww <= ((end - 1) >> 5); ww++) words[ww] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TE_OLD_TRAILER   // diagnostic: round 3's trailer, a plain read-modify-write of the shared word
+        auto or32 = [&](uint32_t wi, uint32_t bits) { words[wi] |= bits; };
+#else
+        auto or32 = [&](uint32_t wi, uint32_t bits) { if (bits) (void)__hip_atomic_fetch_or(&words[wi], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#endif
         for (int k = N - 1; k >= 0; k--) {
             const uint64_t v = (uint64_t)((uint32_t)s_E[(T - 1) * N + k] + size) & (((uint64_t)1 << tl) - 1);  // addBits32NC(state, tl)
             const uint32_t wi = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
-            words[wi] |= (uint32_t)(v << sh);
-            if (sh + tl > 32) words[wi + 1] |= (uint32_t)(v >> (32 - sh));
+            or32(wi, (uint32_t)(v << sh));
+            if (sh + tl > 32) or32(wi + 1, (uint32_t)(v >> (32 - sh)));
             pos += tl;
         }
-        words[pos >> 5] |= 1u << (pos & 31);                            // bitwriter.go:162-168
+        or32((uint32_t)(pos >> 5), 1u << (pos & 31));                   // bitwriter.go:162-168
     }
 #ifdef MIC_GATE_REG2
     total_bytes_out = total_bytes; rc_out = rc_reg;
@@ -1148,7 +1197,11 @@ __global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2
     if (u.status != MICD_OK) return;
     const bool handed = u.nstates_used == -2;                              // the two-state instance gave up on its first attempt (below)
     if (u.nstates_used != 0 && !(WIDTH == 2 && handed)) return;
+#ifdef TE_COMBINED   // diagnostic build: the round-3 layout in which one-state streams differed from call to call
+    if (WIDTH != 0 && ((u.nstates > 2 || u.symbol_len > TTS || handed) ? 2 : 1) != WIDTH) return;
+#else
     if (WIDTH != 0 && ((u.nstates != 2 || u.symbol_len > TTS || handed) ? 2 : 1) != WIDTH) return;   // (1: two states, coding records in LDS)
+#endif
     if ((u.nstates == 108 ? 8 : (int)u.nstates) > e_states) { if (threadIdx.x == 0) u.status = MICD_ERR_INTERNAL; return; }   // (the launcher sizes the LDS for e_states)
     const uint32_t tl = u.table_log;
     if (tl < tl_lo || tl > tl_hi) return;
@@ -1180,7 +1233,9 @@ __global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2
                 else if (WIDTH != 1 && lanes == 8) te_encode<8, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (WIDTH != 1 && lanes == 4) te_encode<4, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
                 else if (lanes == 2) te_encode<2, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
+#ifndef TE_COMBINED
                 else if (WIDTH == 1) rc = MICD_ERR_INTERNAL;                            // (not reached: the two-state instance hands its fall-backs over)
+#endif
                 else te_encode<1, false, true, T, (TLHI <= 15)>(u, s_stab, s_tt, s_E, s_scan, rc, total_bytes);
             } else {
                 if (WIDTH == 1) rc = MICD_ERR_INTERNAL;                                 // (not reached: such units go to the wide instance)
@@ -1192,6 +1247,13 @@ __global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2
             }
         }
         __syncthreads();
+#ifdef TE_CHECK
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            const uint32_t d = __hip_atomic_load(&u.dbg[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d) { if (tid == 0) u.status = -40 - (int)d; return; }
+        }
+#endif
         if (rc == MICD_OK) {
             if (tid == 0) {
                 if (lanes != 1) {
@@ -1209,7 +1271,9 @@ __global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2
         if (tid == 0) { u.count = (uint32_t)rc; u.bits_off = total_bytes; u.flavour = lanes; }   // probe: why the attempt failed
         if (rc == MICD_ERR_CAPACITY && u.tier == 1) rc = MICD_INT_GROW;               // (the staging blob is tier 1's)
         if (lanes == 1 || rc == MICD_ERR_CAPACITY || rc == MICD_INT_GROW || single) { if (tid == 0) u.status = rc; return; }
+#ifndef TE_COMBINED
         if (WIDTH == 1) { if (tid == 0) u.nstates_used = -2; return; }        // the one-state attempt is the wide instance's (it starts over)
+#endif
         __syncthreads();
     }
 }
