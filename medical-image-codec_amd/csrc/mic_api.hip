@@ -223,8 +223,10 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     if (rc) return rc;
     { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false;
+    uint32_t rows_kmask = 0;                                             // chunk classes of the row-by-row predictor this batch holds
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
+        rows_kmask |= mic_rows_kbit(units[i].width);
         const uint64_t len = ends[i] - begins[i];
         u.comp_in = d_blobs + begins[i]; u.comp_len = (uint32_t)len;
         u.px_out = d_pixels_out + units[i].px_offset;
@@ -237,7 +239,7 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p, rows_kmask);
     HIP_TRY(hipGetLastError());
     s->n_last = n;
     return MIC_OK;

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64) k_dec_tans_gl(MicUnit *units) {
 }
 
 
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls) {
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t rows_kmask) {
     const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
     if (t) t->mark("k_dec_tables_wg");
     mic_launch_dec_tables(d_units, n, stream);
@@ -285,6 +285,6 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     hipLaunchKernelGGL(k_dec_tans_gl<8>, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_dec_tans_serial");
     hipLaunchKernelGGL(k_dec_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
-    mic_launch_decode_pixels(d_units, n, stream, t, any_grad);
+    mic_launch_decode_pixels(d_units, n, stream, t, any_grad, rows_kmask);
     if (t) t->mark("end");
 }

@@ -54,9 +54,20 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
 #define MIC_CLS_HEAD 32
 #define MIC_CLS_CLASSES 30
 #define MIC_CLS_INTS(n) (MIC_CLS_HEAD + MIC_CLS_CLASSES * (size_t)(n))
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls);
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t rows_kmask = ~0u);
 void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t);
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false);
+// rows_kmask: chunk classes of k_dec_predict_rows (mic_decode_rows.hip) the batch can hold -- bit (K - 18) / 4; ~0u when the caller does not know its widths
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false, uint32_t rows_kmask = ~0u);
+void mic_launch_decode_rows(MicUnit *d_units, int n, hipStream_t stream, uint32_t kmask);
+// Frames of MIC_ROWS_LO < columns <= MIC_ROWS_HI take the row-by-row predictor: pixels per lane and row (0: another kernel's frame)
+#define MIC_ROWS_LO 1008
+#define MIC_ROWS_HI 2688
+__host__ __device__ inline int mic_rows_k(int w) {
+    if (w <= MIC_ROWS_LO || w > MIC_ROWS_HI) return 0;
+    const int k = (w + 63) >> 6;                    // (16 .. 42; the classes are 18, 22 .. 42: an odd number of dwords per lane, mic_decode_rows.hip)
+    return 18 + 4 * ((max(k, 18) - 18 + 3) / 4);
+}
+__host__ __device__ inline uint32_t mic_rows_kbit(int w) { const int k = mic_rows_k(w); return k ? 1u << ((k - 18) / 4) : 0u; }
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream);
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream);

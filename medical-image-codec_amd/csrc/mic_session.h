@@ -160,30 +160,38 @@ struct mic_hip_session {
         // grow.  Sizing for max(n) x max(px) over a session's history would ask for the bounding box of unrelated calls (one
         // 4-megapixel wavelet frame, then 3000 WSI planes of 256 x 256).
         if (n == max_units && px == max_px && want_tier == tier) return MIC_OK;
+        // From here on the layout is in flux: a reservation that fails half way (DevBuf::reserve frees before it allocates) must not
+        // leave the old shape key standing over new strides and freed slabs -- the next call of the old shape would take the early
+        // return above and hand the kernels null or short slabs.  The key is cleared first and set again only when every slab stands.
+        max_units = 0; max_px = 0; tier = 0;
         int nn = n; size_t pp = px;
         const size_t tokc = tok_cap_tier(pp, want_tier), ts = tab_syms_tier(want_tier);
-        tok_stride = align_up(tokc * 2, 256);
-        blob_stride = align_up(blob_cap_tok(tokc), 256);
-        seg_stride = align_up(seg_cap_tier(pp, want_tier) * 8, 256);
-        sym_stride = align_up((tokc + 64) * 2, 256);       // + a block: the tANS encoder rounds its per-token states up to 32
-        flag_stride = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
-        int rc;
-        if ((rc = units.reserve(sizeof(MicUnit) * (size_t)nn))) return rc;
-        if ((rc = cls.reserve(4 * MIC_CLS_INTS(nn)))) return rc;
-        if ((rc = tok.reserve(tok_stride * (size_t)nn))) return rc;
-        if ((rc = hist.reserve(ts * 4 * (size_t)nn))) return rc;
-        if ((rc = norm.reserve(ts * 4 * (size_t)nn))) return rc;
-        if ((rc = tt_nb.reserve(ts * 4 * (size_t)nn))) return rc;
-        if ((rc = tt_find.reserve(ts * 4 * (size_t)nn))) return rc;
-        if ((rc = state_tab.reserve(ts * 4 * (size_t)nn))) return rc;
-        if ((rc = tab_sym.reserve(ts * 2 * (size_t)nn))) return rc;
-        if ((rc = cumul.reserve((ts + 64) * 4 * (size_t)nn))) return rc;
-        if ((rc = blob.reserve(blob_stride * (size_t)nn))) return rc;
-        if ((rc = offsets.reserve(8 * ((size_t)nn + 1)))) return rc;
-        if ((rc = seg.reserve(seg_stride * (size_t)nn))) return rc;
-        if ((rc = sym.reserve(sym_stride * (size_t)nn))) return rc;
-        if ((rc = flags.reserve(flag_stride * (size_t)nn))) return rc;
+        const size_t tok_s = align_up(tokc * 2, 256);
+        const size_t blob_s = align_up(blob_cap_tok(tokc), 256);
+        const size_t seg_s = align_up(seg_cap_tier(pp, want_tier) * 8, 256);
+        const size_t sym_s = align_up((tokc + 64) * 2, 256);       // + a block: the tANS encoder rounds its per-token states up to 32
+        const size_t flag_s = align_up(pp / 8 + 16, 256);          // + the predictor's 3-word read at the last pixel
+        const int rc = [&]() -> int {
+            int r;
+            if ((r = units.reserve(sizeof(MicUnit) * (size_t)nn))) return r;
+            if ((r = cls.reserve(4 * MIC_CLS_INTS(nn)))) return r;
+            if ((r = tok.reserve(tok_s * (size_t)nn))) return r;
+            if ((r = hist.reserve(ts * 4 * (size_t)nn))) return r;
+            if ((r = norm.reserve(ts * 4 * (size_t)nn))) return r;
+            if ((r = tt_nb.reserve(ts * 4 * (size_t)nn))) return r;
+            if ((r = tt_find.reserve(ts * 4 * (size_t)nn))) return r;
+            if ((r = state_tab.reserve(ts * 4 * (size_t)nn))) return r;
+            if ((r = tab_sym.reserve(ts * 2 * (size_t)nn))) return r;
+            if ((r = cumul.reserve((ts + 64) * 4 * (size_t)nn))) return r;
+            if ((r = blob.reserve(blob_s * (size_t)nn))) return r;
+            if ((r = offsets.reserve(8 * ((size_t)nn + 1)))) return r;
+            if ((r = seg.reserve(seg_s * (size_t)nn))) return r;
+            if ((r = sym.reserve(sym_s * (size_t)nn))) return r;
+            return flags.reserve(flag_s * (size_t)nn);
+        }();
+        if (rc) { hist_unknown(); return rc; }             // (whatever the histogram slab holds now, nothing of it is known to be zero)
         if (ts != tab_syms) hist_unknown();                // (the histogram slabs are laid out anew: nothing is known to be zero)
+        tok_stride = tok_s; blob_stride = blob_s; seg_stride = seg_s; sym_stride = sym_s; flag_stride = flag_s;
         max_units = nn; max_px = pp; tier = want_tier; tab_syms = ts;
         return MIC_OK;
     }
