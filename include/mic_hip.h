@@ -53,6 +53,21 @@ extern "C" {
  * reference's host is ONE process (goroutines, parallelstrips.go:77-93; re-entrancy: ojph/mic_parallel.h:47-48) -- creates
  * one session per device with mic_hip_session_create_on and uses the session entry points. */
 int mic_hip_set_device(int device);
+/* SEVERAL devices for the batch entry points below (mic_hip_compress_batch / _decompress_batch, mic_hip_pics_compress_batch /
+ * _decompress_batch, mic_hip_mic2_compress / _decompress): a call's jobs are cut into one contiguous shard per listed device,
+ * balanced by pixels -- the static assignment of the reference's fan-outs (parallelstrips.go:77-93, multiframecompress.go:186-209,
+ * wsicompress.go:126-145) -- and the shards run side by side, each on a session of its device's pool with its own sub-batch
+ * pipeline and transfer streams; results are written straight into the caller's buffers (no gather: the caller's memory is the
+ * whole view).  This is how ONE host process -- the reference's host is one Go process -- gets past a single PCIe link: eight GPUs
+ * are eight links.  devices[0] is also the device of every other host-pointer entry point; a device may be listed twice (two
+ * shards on one GPU).  Waits for running calls; MIC_ERR_DEVICE when a device does not exist or is not gfx950.
+ * mic_hip_get_devices: the current list (returns its length; at most cap entries are written). */
+int mic_hip_set_devices(const int *devices, int n);
+int mic_hip_get_devices(int *devices, int cap);
+/* The cut those calls make, for callers that want to lay their work out to match it: n items of the given weights (pixels) into
+ * `shards` contiguous shards -- item i belongs to shard k iff first[k] <= i < first[k + 1]; first has shards + 1 entries.
+ * Needs no device. */
+int mic_hip_shard_plan(const uint64_t *weights, int n, int shards, int *first);
 /* "gfx950 <n CUs> ..." style description of the active device; "" if none. */
 const char *mic_hip_device_name(void);
 const char *mic_hip_version(void);
@@ -151,6 +166,12 @@ void  mic_hip_host_free(void *p);
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height,
                           uint16_t max_value, int num_strips, int nstates,
                           uint8_t *out, size_t out_cap, size_t *out_len);
+/* The same with the index of the strip the error belongs to (the reference wraps it: "parallelstrips: strip %d: %w",
+ * parallelstrips.go:97): *failed_strip = the first strip whose codec failed, -1 when the call succeeded or the error is not a
+ * strip's (arguments, capacity of the header, the device). */
+int mic_hip_pics_compress_ex(const uint16_t *pixels, int width, int height,
+                             uint16_t max_value, int num_strips, int nstates,
+                             uint8_t *out, size_t out_cap, size_t *out_len, int *failed_strip);
 /* Header probe (parallelstrips.go:271-286). */
 int mic_hip_pics_info(const uint8_t *compressed, size_t compressed_len,
                       int *width, int *height, int *num_strips, int *strip_height);
@@ -159,6 +180,9 @@ int mic_hip_pics_info(const uint8_t *compressed, size_t compressed_len,
  * width/height must equal the header's. */
 int mic_hip_pics_decompress(const uint8_t *compressed, size_t compressed_len,
                             uint16_t *pixels_out, int width, int height);
+/* ... and with the index of the strip that failed to decode ("parallelstrips: strip %d: %w", parallelstrips.go:316; -1: none). */
+int mic_hip_pics_decompress_ex(const uint8_t *compressed, size_t compressed_len,
+                               uint16_t *pixels_out, int width, int height, int *failed_strip);
 /* Many images, one call: the strips of ALL jobs are one unit batch (the reference reaches the same parallelism by calling
  * CompressParallelStrips from many goroutines, each fanning out its strips: parallelstrips.go:77-93; a single image is eight
  * serial entropy chains and leaves the device idle).  Every job's file equals mic_hip_pics_compress's, byte for byte. */
@@ -172,6 +196,7 @@ typedef struct mic_hip_pics_enc_job {
     size_t    out_cap;        /* in  */
     size_t    out_len;        /* out */
     int32_t   status;         /* out */
+    int32_t   failed_strip;   /* out: the first strip whose codec failed (parallelstrips.go:97), -1: none / not a strip's error */
 } mic_hip_pics_enc_job;
 typedef struct mic_hip_pics_dec_job {
     const uint8_t *compressed; /* in : a PICS file (host memory) */
@@ -179,6 +204,7 @@ typedef struct mic_hip_pics_dec_job {
     uint16_t *pixels_out;      /* in : width*height u16 (host memory) */
     int32_t   width, height;   /* in : must equal the header's */
     int32_t   status;          /* out */
+    int32_t   failed_strip;    /* out: the first strip that failed to decode (parallelstrips.go:316), -1: none */
 } mic_hip_pics_dec_job;
 int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs);
 int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs);

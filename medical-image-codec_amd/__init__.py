@@ -79,12 +79,14 @@ class DecJob(C.Structure):
 class PicsEncJob(C.Structure):
     _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
                 ("max_value", C.c_uint16), ("nstates", C.c_uint16), ("num_strips", C.c_int32),
-                ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_len", C.c_size_t), ("status", C.c_int32)]
+                ("out", C.c_void_p), ("out_cap", C.c_size_t), ("out_len", C.c_size_t), ("status", C.c_int32),
+                ("failed_strip", C.c_int32)]
 
 
 class PicsDecJob(C.Structure):
     _fields_ = [("compressed", C.c_void_p), ("compressed_len", C.c_size_t),
-                ("pixels_out", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("status", C.c_int32)]
+                ("pixels_out", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("status", C.c_int32),
+                ("failed_strip", C.c_int32)]
 
 
 class Unit(C.Structure):
@@ -94,11 +96,12 @@ class Unit(C.Structure):
 
 # every symbol include/mic_hip.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
-    "mic_hip_set_device", "mic_hip_device_name", "mic_hip_version",
+    "mic_hip_set_device", "mic_hip_set_devices", "mic_hip_get_devices", "mic_hip_shard_plan", "mic_hip_device_name", "mic_hip_version",
     "mic_hip_compress_frame", "mic_hip_decompress_frame",
     "mic_hip_fse_compress_u16", "mic_hip_fse_decompress_u16_auto", "mic_hip_fse_compress_u16_ex", "mic_hip_fse_decompress_u16_ex",
     "mic_hip_compress_batch", "mic_hip_decompress_batch", "mic_hip_host_alloc", "mic_hip_host_free",
-    "mic_hip_pics_compress", "mic_hip_pics_info", "mic_hip_pics_decompress", "mic_hip_pics_compress_batch", "mic_hip_pics_decompress_batch",
+    "mic_hip_pics_compress", "mic_hip_pics_compress_ex", "mic_hip_pics_info", "mic_hip_pics_decompress", "mic_hip_pics_decompress_ex",
+    "mic_hip_pics_compress_batch", "mic_hip_pics_decompress_batch",
     "mic_hip_mic2_compress", "mic_hip_mic2_compress_temporal", "mic_hip_mic2_info", "mic_hip_mic2_decompress",
     "mic_hip_mic2_decompress_frame",
     "mic_hip_wavelet_v2_compress", "mic_hip_wavelet_v2_compress_batch", "mic_hip_wavelet_v2_decompress_batch", "mic_hip_wavelet_v2_info", "mic_hip_wavelet_v2_decompress",
@@ -184,6 +187,11 @@ def lib() -> C.CDLL:
     L.mic_hip_decompress_batch.argtypes = [C.POINTER(DecJob), C.c_int]
     L.mic_hip_pics_compress.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint16, C.c_int, C.c_int,
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mic_hip_pics_compress_ex.argtypes = L.mic_hip_pics_compress.argtypes + [C.POINTER(C.c_int)]
+    L.mic_hip_pics_decompress_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.mic_hip_set_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.mic_hip_get_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.mic_hip_shard_plan.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.mic_hip_pics_compress_batch.argtypes = [C.POINTER(PicsEncJob), C.c_int]
     L.mic_hip_pics_decompress_batch.argtypes = [C.POINTER(PicsDecJob), C.c_int]
     L.mic_hip_host_alloc.argtypes = [C.c_size_t]
@@ -348,17 +356,46 @@ def decompress_batch(blobs: Sequence[bytes], dims: Sequence[Tuple[int, int]]) ->
 
 # ------------------------------------------------------------------ PICS
 def compress_parallel_strips(pixels, width: int, height: int, max_value: int, num_strips: int, nstates: int = 2) -> bytes:
-    """CompressParallelStrips / 4State / 8State (parallelstrips.go:55,128,199)."""
+    """CompressParallelStrips / 4State / 8State (parallelstrips.go:55,128,199); a strip's error carries its index, as the
+    reference's "parallelstrips: strip %d: %w" does (:97): MicError.strip."""
     px = _u16(pixels).reshape(-1)
     if px.size != width * height:
         raise MicError(MIC_ERR_ARGS, "parallelstrips: pixel count != width*height")
     cap = px.size * 4 + 135168 * max(num_strips, 1) + 8 * max(num_strips, 1) + 20
     out = np.empty(cap, dtype=np.uint8)
-    n = C.c_size_t(0)
-    rc = lib().mic_hip_pics_compress(px.ctypes.data, width, height, max_value, num_strips, nstates, out.ctypes.data, cap, C.byref(n))
+    n = C.c_size_t(0); bad = C.c_int(-1)
+    rc = lib().mic_hip_pics_compress_ex(px.ctypes.data, width, height, max_value, num_strips, nstates, out.ctypes.data, cap, C.byref(n), C.byref(bad))
     if rc:
-        _raise(rc, "compress_parallel_strips")
+        try:
+            _raise(rc, "parallelstrips" + (f": strip {bad.value}" if bad.value >= 0 else ""))
+        except MicError as e:
+            e.strip = bad.value
+            raise
     return out[: n.value].tobytes()
+
+
+def set_devices(devices: Sequence[int]) -> None:
+    """mic_hip_set_devices: the GPUs the batch entry points spread their jobs over (the first is the default device)."""
+    arr = (C.c_int * len(devices))(*devices)
+    rc = lib().mic_hip_set_devices(arr, len(devices))
+    if rc:
+        _raise(rc, "set_devices")
+
+
+def get_devices() -> List[int]:
+    arr = (C.c_int * 64)()
+    n = lib().mic_hip_get_devices(arr, 64)
+    return [arr[i] for i in range(min(n, 64))]
+
+
+def shard_plan(weights: Sequence[int], shards: int) -> List[int]:
+    """mic_hip_shard_plan: first[0..shards] of the contiguous cut the batch entry points make over several devices."""
+    w = (C.c_uint64 * len(weights))(*[int(x) for x in weights])
+    first = (C.c_int * (shards + 1))()
+    rc = lib().mic_hip_shard_plan(w, len(weights), shards, first)
+    if rc:
+        _raise(rc, "shard_plan")
+    return list(first)
 
 
 def pics_bound(width: int, height: int, num_strips: int) -> int:
@@ -383,6 +420,7 @@ def compress_parallel_strips_batch(images: Sequence[np.ndarray], max_value: int,
     rc = lib().mic_hip_pics_compress_batch(jobs, n)
     if rc:
         _raise(rc, "compress_parallel_strips_batch")
+    compress_parallel_strips_batch.failed_strips = [jobs[i].failed_strip for i in range(n)]     # (of the last call: index of each job's failing strip, -1)
     return [(jobs[i].status, outs[i][: jobs[i].out_len]) for i in range(n)]
 
 
@@ -437,9 +475,14 @@ def decompress_parallel_strips(compressed) -> Tuple[np.ndarray, int, int]:
     c = _bytes_arr(compressed)
     w, h, _, _ = pics_info(c)
     out = np.empty(w * h, dtype=np.uint16)
-    rc = lib().mic_hip_pics_decompress(c.ctypes.data, c.size, out.ctypes.data, w, h)
+    bad = C.c_int(-1)
+    rc = lib().mic_hip_pics_decompress_ex(c.ctypes.data, c.size, out.ctypes.data, w, h, C.byref(bad))
     if rc:
-        _raise(rc, "decompress_parallel_strips")
+        try:
+            _raise(rc, "parallelstrips" + (f": strip {bad.value}" if bad.value >= 0 else ""))
+        except MicError as e:
+            e.strip = bad.value
+            raise
     return out.reshape(h, w), w, h
 
 

@@ -14,13 +14,17 @@ namespace micapi {
 // one session behind one mutex would serialise every goroutine of a Go host): a call leases a free session for its duration,
 // creates one while the pool is below its size (MIC_HIP_POOL, default 3), waits otherwise.  g_mu guards the device choice and
 // the pool's lists; a leased session is used without any lock.
+// Several devices (mic_hip_set_devices): a pool per device; the batch entry points cut their jobs into one contiguous shard per
+// listed device and run the shards side by side, each on a session of its device's pool (mic_host_io.hip).  g_device is the first
+// of the list: what every other host-pointer entry point runs on.
 std::mutex g_mu;
 std::condition_variable g_pool_cv;
 int g_device = 0;
+std::vector<int> g_devices(1, 0);
 bool g_device_ok = false;
 std::string g_device_name;
-std::vector<mic_hip_session *> g_pool_free;
-int g_pool_made = 0;
+struct DevPool { std::vector<mic_hip_session *> free_; int made = 0; };
+std::map<int, DevPool> g_pools;                        // by device
 thread_local mic_hip_session *tl_default = nullptr;   // the session the calling thread holds (leases nest: containers call the unit codec)
 thread_local int tl_depth = 0;
 
@@ -61,18 +65,21 @@ int ensure_device() { std::lock_guard<std::mutex> lk(g_mu); return ensure_device
 
 mic_hip_session *cur_default() { return tl_default; }
 
-int DefaultLease::acquire() {
+int DefaultLease::acquire(int device) {
     if (tl_default) {                                                   // nested call on this thread: the session it already holds
         s = tl_default; tl_depth++; held = true;
         return s->activate();
     }
     {
         std::unique_lock<std::mutex> lk(g_mu);
-        const int rc = ensure_device_locked();
+        int rc = ensure_device_locked();
         if (rc) return rc;
-        while (g_pool_free.empty() && g_pool_made >= pool_max()) g_pool_cv.wait(lk);
-        if (!g_pool_free.empty()) { s = g_pool_free.back(); g_pool_free.pop_back(); }
-        else { s = new mic_hip_session(); s->device = g_device; g_pool_made++; }
+        if (device < 0) device = g_device;
+        else if (std::find(g_devices.begin(), g_devices.end(), device) == g_devices.end()) return MIC_ERR_ARGS;
+        DevPool &pool = g_pools[device];
+        while (pool.free_.empty() && pool.made >= pool_max()) g_pool_cv.wait(lk);
+        if (!pool.free_.empty()) { s = pool.free_.back(); pool.free_.pop_back(); }
+        else { s = new mic_hip_session(); s->device = device; pool.made++; }
     }
     tl_default = s; tl_depth = 1; held = true;
     int rc = s->activate();
@@ -85,9 +92,10 @@ DefaultLease::~DefaultLease() {
     if (--tl_depth > 0) return;
     tl_default = nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_pool_free.push_back(s);
-    g_pool_cv.notify_one();
+    g_pools[s->device].free_.push_back(s);
+    g_pool_cv.notify_all();
 }
+std::vector<int> default_devices() { std::lock_guard<std::mutex> lk(g_mu); return g_devices; }
 
 // Per-call workspace ceiling (the container entry points cut their unit lists into sub-batches that stay under it): what the session
 // already holds, or -- never more than a quarter of the device -- half of what is free right now, so that several sessions on one GPU
@@ -128,7 +136,23 @@ static int encode_enqueue_tier(mic_hip_session *s, const uint16_t *d_pixels, con
     s->timer.reset(s->stream);
     mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0) | (narrow ? MIC_VARIANT_NARROW : 0), &s->timer);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
-    s->n_last = n;
+    s->begin_chain(n);
+    // Compaction and the read-back of the results ride behind the chain, so that session_encode_finish is ONE synchronisation (round 3:
+    // descriptors down, a synchronisation, sizes summed on the host, scan + pack launched, a second synchronisation -- 86 us of idle
+    // device between the chain and the pack of every call).  The packed buffer is sized from what the session's last batch needed;
+    // k_enc_pack leaves a batch that does not fit alone and finish packs it again into a buffer of the right size.
+    {
+        size_t raw = 0;
+        for (int i = 0; i < n; i++) raw += (size_t)units[i].width * (size_t)units[i].height * 2;
+        const size_t want = std::max(s->pack_hint + s->pack_hint / 8, raw / 3) + ((size_t)64 << 10);
+        if ((rc = s->packed.reserve(want))) return rc;
+        if ((rc = s->pin_off.reserve((size_t)n + 1))) return rc;
+        mic_launch_pack((const MicUnit *)s->units.p, n, (uint64_t *)s->offsets.p, (uint8_t *)s->packed.p, (uint64_t)s->packed.cap, s->stream, &s->timer);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->pin_off.p, s->offsets.p, 8 * ((size_t)n + 1), hipMemcpyDeviceToHost, s->stream));
+        s->readback_queued = true; s->pack_queued = true; s->pack_cap = s->packed.cap;
+    }
     return MIC_OK;
 }
 
@@ -154,7 +178,8 @@ int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const m
 // reads the units back; a tier-1 chain that reported MICD_INT_GROW somewhere is run again in tier 2 first
 static int finish_units(mic_hip_session *s, int n) {
     for (int pass = 0; pass < 2; pass++) {
-        HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        if (!s->readback_queued) HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        s->readback_queued = false;
         HIP_TRY(hipStreamSynchronize(s->stream));
         bool grow = false;
         for (int i = 0; i < n; i++) grow |= s->h_units[(size_t)i].status == MICD_INT_GROW;
@@ -184,11 +209,16 @@ int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t 
         if (h_nstates) h_nstates[i] = u.nstates_used;
     }
     h_offsets[n] = total;
-    int rc = s->packed.reserve((size_t)total + 16);
-    if (rc) return rc;
-    mic_launch_pack((const MicUnit *)s->units.p, n, (uint64_t *)s->offsets.p, (uint8_t *)s->packed.p, s->stream, nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    const bool packed_already = s->pack_queued && (size_t)total + 16 <= s->pack_cap && s->pin_off.cap > (size_t)n && s->pin_off.p[n] == total;
+    s->pack_queued = false;
+    s->pack_hint = (size_t)total;
+    if (!packed_already) {                         // a caller that launched its own chain, or a batch larger than the session's last
+        int rc = s->packed.reserve((size_t)total + 16);
+        if (rc) return rc;
+        mic_launch_pack((const MicUnit *)s->units.p, n, (uint64_t *)s->offsets.p, (uint8_t *)s->packed.p, (uint64_t)s->packed.cap, s->stream, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     if (d_blobs) *d_blobs = (const uint8_t *)s->packed.p;
     return MIC_OK;
 }
@@ -241,7 +271,9 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p, rows_kmask);
     HIP_TRY(hipGetLastError());
-    s->n_last = n;
+    s->begin_chain(n);
+    HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    s->readback_queued = true;
     return MIC_OK;
 }
 
@@ -290,17 +322,34 @@ int mic_hip_device_copy(void *d_dst, const void *d_src, size_t bytes) {
     return MIC_OK;
 }
 
-int mic_hip_set_device(int device) {
-    if (device < 0) return MIC_ERR_ARGS;
-    std::unique_lock<std::mutex> lk(g_mu);
-    if (g_device_ok && device != g_device) {
-        // the pool moves with the device: wait for every leased session to come back, then drop them
-        while ((int)g_pool_free.size() != g_pool_made) g_pool_cv.wait(lk);
-        for (mic_hip_session *p : g_pool_free) { (void)p->activate(); p->release(); delete p; }
-        g_pool_free.clear(); g_pool_made = 0; g_device_ok = false;
+int mic_hip_set_device(int device) { return mic_hip_set_devices(&device, 1); }
+
+int mic_hip_set_devices(const int *devices, int n) {
+    if (!devices || n <= 0 || n > 64) return MIC_ERR_ARGS;
+    for (int i = 0; i < n; i++) {
+        if (devices[i] < 0) return MIC_ERR_ARGS;
+        const int rc = check_device(devices[i]);
+        if (rc) return rc;
     }
-    g_device = device;
+    std::unique_lock<std::mutex> lk(g_mu);
+    // the pools move with the list: wait for every leased session to come back, then drop those of devices that left it
+    auto all_home = [&] { for (auto &kv : g_pools) if ((int)kv.second.free_.size() != kv.second.made) return false; return true; };
+    while (!all_home()) g_pool_cv.wait(lk);
+    for (auto it = g_pools.begin(); it != g_pools.end();) {
+        if (std::find(devices, devices + n, it->first) == devices + n) {
+            for (mic_hip_session *p : it->second.free_) { (void)p->activate(); p->release(); delete p; }
+            it = g_pools.erase(it);
+        } else ++it;
+    }
+    g_devices.assign(devices, devices + n);
+    if (g_device != devices[0]) g_device_ok = false;
+    g_device = devices[0];
     return ensure_device_locked();
+}
+int mic_hip_get_devices(int *devices, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < (int)g_devices.size() && i < cap; i++) if (devices) devices[i] = g_devices[(size_t)i];
+    return (int)g_devices.size();
 }
 
 const char *mic_hip_device_name(void) {
@@ -359,7 +408,7 @@ int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, 
     if ((rc = s->prepare_hist(1))) return rc;
     mic_launch_encode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
-    s->n_last = 1;
+    s->begin_chain(1);
     uint64_t offs[2]; int32_t st = 0, ns = 0; const uint8_t *d_blobs = nullptr;
     if ((rc = session_encode_finish(s, &d_blobs, offs, &st, &ns))) return rc;
     if (st != MIC_OK) return st;
@@ -403,7 +452,7 @@ int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t deco
     { const int urc = s->h_units.upload(s->units.p, 1, s->stream); if (urc) return urc; }
     mic_launch_decode((MicUnit *)s->units.p, 1, s->stream, s->variant, nullptr, (int *)s->cls.p);
     HIP_TRY(hipGetLastError());
-    s->n_last = 1;
+    s->begin_chain(1);
     int32_t st = 0;
     if ((rc = session_decode_finish(s, &st))) return rc;
     if (st != MIC_OK) return st;

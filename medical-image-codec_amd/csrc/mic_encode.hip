@@ -1281,9 +1281,10 @@ __global__ void __launch_bounds__(T, T != 512 ? 4 : TLHI <= 13 ? (WIDTH == 2 ? 2
 // ------------------------------------------------------------------------------------------
 // Compaction: copy every unit's staging blob to its final offset.  grid = (chunks, units).
 // dst_off[i] = byte offset of unit i in `dst` (exclusive scan of blob_len, done by k_scan_lens).
-__global__ void __launch_bounds__(256) k_enc_pack(const MicUnit *units, const uint64_t *dst_off, uint8_t *dst) {
+__global__ void __launch_bounds__(256) k_enc_pack(const MicUnit *units, const uint64_t *dst_off, uint8_t *dst, uint64_t cap, int n) {
     const MicUnit &u = units[blockIdx.y];
     if (u.status != MICD_OK) return;
+    if (dst_off[n] + 16 > cap) return;                                   // (the batch does not fit: the host packs it again into a larger buffer)
     const mic_gp<const uint8_t> src = mic_g((const uint8_t *)u.blob) + (u.nstates_used == 1 ? 6 : 0);
     const mic_gp<uint8_t> d = mic_g(dst) + dst_off[blockIdx.y];
     // 16 bytes per thread and step; neither side is aligned (gfx950 runs vector memory in unaligned mode)
@@ -1365,10 +1366,10 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     hipLaunchKernelGGL(k_enc_hist_clean, dim3(n), dim3(256), 0, stream, d_units);
     if (t) t->mark("end");
 }
-void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t) {
+void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, uint64_t d_cap, hipStream_t stream, MicTimer *t) {
     if (t) t->mark("k_scan_lens");
     hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, stream, d_units, n, d_off);
     if (t) t->mark("k_enc_pack");
-    hipLaunchKernelGGL(k_enc_pack, dim3(32, n), dim3(256), 0, stream, d_units, d_off, d_dst);
+    hipLaunchKernelGGL(k_enc_pack, dim3(32, n), dim3(256), 0, stream, d_units, d_off, d_dst, d_cap, n);
     if (t) t->mark("end");
 }

@@ -175,6 +175,7 @@ struct EncGroup {
     const uint16_t *h_px; uint8_t *out; size_t out_cap, hdr;
     int first, n;
     size_t written = 0; int32_t status = MIC_OK;
+    int failed = -1;                                  // the group's first unit that failed, counted from `first` ("strip %d", parallelstrips.go:97)
 };
 struct EncUnit {
     uint64_t px_off; int32_t w, h; uint16_t maxv, nstates; int group;
@@ -184,6 +185,7 @@ struct DecGroup {
     const uint8_t *h_comp; uint16_t *h_px;
     int first, n;
     int32_t status = MIC_OK;
+    int failed = -1;
 };
 struct DecUnit {
     size_t comp_off, comp_len; uint64_t px_off; int32_t w, h; uint16_t flags; int group;
@@ -274,7 +276,7 @@ int encode_groups(mic_hip_session *s, std::vector<EncGroup> &G, std::vector<EncU
                 EncUnit &u = U[(size_t)q];
                 u.status = st[(size_t)(q - sb.i0)]; u.nstates_used = ns[(size_t)(q - sb.i0)];
                 u.len = (size_t)(offs[(size_t)(q - sb.i0) + 1] - offs[(size_t)(q - sb.i0)]);
-                if (u.status != MIC_OK && g.status == MIC_OK) g.status = u.status;      // the first failing unit names the error
+                if (u.status != MIC_OK && g.status == MIC_OK) { g.status = u.status; g.failed = q - g.first; }   // the first failing unit names the error
                 bytes += u.len;
             }
             if (g.status == MIC_OK) {
@@ -362,7 +364,7 @@ int decode_groups(mic_hip_session *s, std::vector<DecGroup> &G, std::vector<DecU
             while (j < sb.i1 && U[(size_t)j].group == U[(size_t)i].group) j++;
             for (int q = i; q < j; q++) {
                 U[(size_t)q].status = st[(size_t)(q - sb.i0)];
-                if (U[(size_t)q].status != MIC_OK && g.status == MIC_OK) g.status = U[(size_t)q].status;
+                if (U[(size_t)q].status != MIC_OK && g.status == MIC_OK) { g.status = U[(size_t)q].status; g.failed = q - g.first; }
             }
             if (g.status == MIC_OK) {                      // runs of units whose pixels are neighbours in the host buffer
                 for (int q = i; q < j;) {
@@ -380,6 +382,86 @@ int decode_groups(mic_hip_session *s, std::vector<DecGroup> &G, std::vector<DecU
     for (auto &sb : subs) { const int r2 = sb->up.wait(); const int r3 = sb->down.wait(); if (rc == MIC_OK) rc = r2 ? r2 : r3; }
     mark("all pixels on the host", subs.size());
     return rc;
+}
+
+// ============================================================================ several devices
+// mic_hip_set_devices lists the GPUs the batch entry points may use.  A call's groups (jobs, images) are cut into one CONTIGUOUS
+// shard per listed device, balanced by pixels -- the static assignment of the reference's fan-outs (parallelstrips.go:77-93,
+// multiframecompress.go:186-209, wsicompress.go:126-145) -- and the shards run side by side, each on a thread of its own with a
+// session of its device's pool, its own sub-batch pipeline and the transfer engine's per-device streams and pinned slots.  Results
+// go straight into the caller's buffers: the caller's memory is what a rank-0 view would be, there is no gather.  (A device may be
+// listed twice: two shards, two sessions of one GPU.)
+// first[k] .. first[k + 1]: the items of shard k; boundary k is where the running weight first reaches k / shards of the total
+void shard_plan(const uint64_t *w, int n, int shards, int *first) {
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) total += w[i] ? w[i] : 1;
+    first[0] = 0;
+    uint64_t run = 0; int i = 0;
+    for (int k = 1; k < shards; k++) {
+        const uint64_t goal = (uint64_t)(((unsigned __int128)total * (unsigned)k) / (unsigned)shards);
+        while (i < n && run < goal) { run += w[i] ? w[i] : 1; i++; }
+        first[k] = i;
+    }
+    first[shards] = n;
+}
+
+template <class Grp, class Unt, class Run>
+int run_shards(std::vector<Grp> &G, std::vector<Unt> &U, Run run_one) {
+    const std::vector<int> devs = default_devices();
+    const int ng = (int)G.size();
+    int shards = (int)std::min<size_t>(devs.size(), (size_t)ng);
+    if (cur_default()) shards = 1;                    // (a nested call runs on the session its thread already holds)
+    if (shards <= 1) {
+        DefaultLease lease;
+        const int rc = lease.acquire();
+        return rc ? rc : run_one(lease.s, G, U);
+    }
+    std::vector<uint64_t> w((size_t)ng);
+    for (int g = 0; g < ng; g++) {
+        uint64_t px = 0;
+        for (int q = G[(size_t)g].first; q < G[(size_t)g].first + G[(size_t)g].n; q++) px += (uint64_t)U[(size_t)q].w * (uint64_t)U[(size_t)q].h;
+        w[(size_t)g] = px;
+    }
+    std::vector<int> first((size_t)shards + 1);
+    shard_plan(w.data(), ng, shards, first.data());
+    struct Shard { std::vector<Grp> G; std::vector<Unt> U; int rc = MIC_OK; };
+    std::vector<Shard> S((size_t)shards);
+    for (int k = 0; k < shards; k++) {
+        const int g0 = first[(size_t)k], g1 = first[(size_t)k + 1];
+        if (g0 == g1) continue;
+        const int u0 = G[(size_t)g0].first, u1 = G[(size_t)g1 - 1].first + G[(size_t)g1 - 1].n;
+        S[(size_t)k].G.assign(G.begin() + g0, G.begin() + g1);
+        S[(size_t)k].U.assign(U.begin() + u0, U.begin() + u1);
+        for (Grp &g : S[(size_t)k].G) g.first -= u0;
+        for (Unt &u : S[(size_t)k].U) u.group -= g0;
+    }
+    auto work = [&](int k) {
+        if (S[(size_t)k].G.empty()) return;
+        DefaultLease lease;
+        int rc = lease.acquire(devs[(size_t)k]);
+        if (rc == MIC_OK) rc = run_one(lease.s, S[(size_t)k].G, S[(size_t)k].U);
+        S[(size_t)k].rc = rc;
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < shards; k++) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    int rc = MIC_OK;
+    for (int k = 0; k < shards; k++) {
+        if (S[(size_t)k].rc != MIC_OK && rc == MIC_OK) rc = S[(size_t)k].rc;
+        const int g0 = first[(size_t)k];
+        if (S[(size_t)k].G.empty()) continue;
+        const int u0 = G[(size_t)g0].first;
+        for (size_t i = 0; i < S[(size_t)k].G.size(); i++) { Grp g = S[(size_t)k].G[i]; g.first += u0; G[(size_t)g0 + i] = g; }
+        for (size_t i = 0; i < S[(size_t)k].U.size(); i++) { Unt u = S[(size_t)k].U[i]; u.group += g0; U[(size_t)u0 + i] = u; }
+    }
+    return rc;
+}
+int encode_sharded(std::vector<EncGroup> &G, std::vector<EncUnit> &U) {
+    return run_shards(G, U, [](mic_hip_session *s, std::vector<EncGroup> &g, std::vector<EncUnit> &u) { return encode_groups(s, g, u); });
+}
+int decode_sharded(std::vector<DecGroup> &G, std::vector<DecUnit> &U) {
+    return run_shards(G, U, [](mic_hip_session *s, std::vector<DecGroup> &g, std::vector<DecUnit> &u) { return decode_groups(s, g, u); });
 }
 
 // the strips of a PICS image (parallelstrips.go:59-72)
@@ -403,11 +485,18 @@ int host_copy(int device, void *dev, void *host, size_t bytes, bool to_device) {
 // ================================================================================ C ABI
 extern "C" {
 
+// The cut of `n` weighted items into `shards` contiguous shards that the batch entry points use across the devices of
+// mic_hip_set_devices (first[0 .. shards]: item i belongs to shard k iff first[k] <= i < first[k + 1]); no device needed.
+int mic_hip_shard_plan(const uint64_t *weights, int n, int shards, int *first) {
+    if (!weights || !first || n < 0 || shards <= 0) return MIC_ERR_ARGS;
+    shard_plan(weights, n, shards, first);
+    return MIC_OK;
+}
+
 // Pinned host memory for a caller's frame and stream buffers: the entry points below DMA such buffers in place instead of
 // staging them through the transfer engine's slots.
 void *mic_hip_host_alloc(size_t bytes) {
-    DefaultLease lease;
-    if (lease.acquire() != MIC_OK) return nullptr;
+    if (ensure_device() != MIC_OK) return nullptr;                       // (makes the default device current; no session is held or made)
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
@@ -417,8 +506,7 @@ void mic_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
-    DefaultLease lease;
-    int rc = lease.acquire();
+    int rc = ensure_device();
     if (rc) return rc;
     std::vector<EncGroup> G; std::vector<EncUnit> U; std::vector<int> job_of;
     for (int i = 0; i < njobs; i++) {
@@ -430,7 +518,7 @@ int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
         U.push_back(EncUnit{ 0, j.width, j.height, j.max_value, j.nstates, (int)G.size() - 1 });
         job_of.push_back(i);
     }
-    if ((rc = encode_groups(lease.s, G, U))) return rc;
+    if ((rc = encode_sharded(G, U))) return rc;
     for (size_t k = 0; k < G.size(); k++) {
         mic_hip_enc_job &j = jobs[job_of[k]];
         j.status = G[k].status; j.nstates_used = U[k].nstates_used;
@@ -442,8 +530,7 @@ int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
 int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
-    DefaultLease lease;
-    int rc = lease.acquire();
+    int rc = ensure_device();
     if (rc) return rc;
     std::vector<DecGroup> G; std::vector<DecUnit> U; std::vector<int> job_of;
     for (int i = 0; i < njobs; i++) {
@@ -456,7 +543,7 @@ int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
         U.push_back(DecUnit{ 0, j.compressed_len, 0, j.width, j.height, 0, (int)G.size() - 1 });
         job_of.push_back(i);
     }
-    if ((rc = decode_groups(lease.s, G, U))) return rc;
+    if ((rc = decode_sharded(G, U))) return rc;
     for (size_t k = 0; k < G.size(); k++) jobs[job_of[k]].status = G[k].status;
     return MIC_OK;
 }
@@ -465,15 +552,14 @@ int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
 int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
-    DefaultLease lease;
-    int rc = lease.acquire();
+    int rc = ensure_device();
     if (rc) return rc;
     std::vector<EncGroup> G; std::vector<EncUnit> U; std::vector<int> job_of;
     struct Geo { int strip_h, actual; };
     std::vector<Geo> geo;
     for (int i = 0; i < njobs; i++) {
         mic_hip_pics_enc_job &j = jobs[i];
-        j.out_len = 0;
+        j.out_len = 0; j.failed_strip = -1;
         if (!j.pixels || !j.out || j.width <= 0 || j.height <= 0 || j.num_strips <= 0 || !(j.nstates == 2 || j.nstates == 4 || j.nstates == 8)) { j.status = MIC_ERR_ARGS; continue; }
         int strip_h, actual; pics_geometry(j.height, j.num_strips, strip_h, actual);
         const size_t header = 20 + (size_t)actual * 8;
@@ -486,11 +572,12 @@ int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) {
         }
         job_of.push_back(i); geo.push_back(Geo{ strip_h, actual });
     }
-    if ((rc = encode_groups(lease.s, G, U))) return rc;
+    if ((rc = encode_sharded(G, U))) return rc;
     for (size_t k = 0; k < G.size(); k++) {
         mic_hip_pics_enc_job &j = jobs[job_of[k]];
         const EncGroup &g = G[k];
         j.status = g.status;                                                   // first failing strip, :95-99
+        j.failed_strip = g.failed;                                             // "parallelstrips: strip %d: %w", :97
         if (j.status != MIC_OK) continue;
         if (g.written > 0xFFFFFFFFull) { j.status = MIC_ERR_UNSUPPORTED; continue; }
         uint8_t *out = j.out;
@@ -511,6 +598,11 @@ int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) {
 
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
                           uint8_t *out, size_t out_cap, size_t *out_len) {
+    return mic_hip_pics_compress_ex(pixels, width, height, max_value, num_strips, nstates, out, out_cap, out_len, nullptr);
+}
+int mic_hip_pics_compress_ex(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
+                             uint8_t *out, size_t out_cap, size_t *out_len, int *failed_strip) {
+    if (failed_strip) *failed_strip = -1;
     if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
     if (!(nstates == 2 || nstates == 4 || nstates == 8)) return MIC_ERR_ARGS;
     mic_hip_pics_enc_job j{};
@@ -519,18 +611,19 @@ int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_
     const int rc = mic_hip_pics_compress_batch(&j, 1);
     if (rc) return rc;
     if (j.status == MIC_OK) *out_len = j.out_len;
+    else if (failed_strip) *failed_strip = j.failed_strip;
     return j.status;
 }
 
 int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs) {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
-    DefaultLease lease;
-    int rc = lease.acquire();
+    int rc = ensure_device();
     if (rc) return rc;
     std::vector<DecGroup> G; std::vector<DecUnit> U; std::vector<int> job_of;
     for (int i = 0; i < njobs; i++) {
         mic_hip_pics_dec_job &j = jobs[i];
+        j.failed_strip = -1;
         if (!j.compressed || !j.pixels_out) { j.status = MIC_ERR_ARGS; continue; }
         int w, h, n, sh;
         if ((j.status = mic_hip_pics_info(j.compressed, j.compressed_len, &w, &h, &n, &sh))) continue;
@@ -557,16 +650,21 @@ int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs) {
         G.push_back(DecGroup{ c, j.pixels_out, (int)u0, n });
         job_of.push_back(i);
     }
-    if ((rc = decode_groups(lease.s, G, U))) return rc;
-    for (size_t k = 0; k < G.size(); k++) jobs[job_of[k]].status = G[k].status;
+    if ((rc = decode_sharded(G, U))) return rc;
+    for (size_t k = 0; k < G.size(); k++) { jobs[job_of[k]].status = G[k].status; jobs[job_of[k]].failed_strip = G[k].failed; }   // "strip %d: %w", parallelstrips.go:316
     return MIC_OK;
 }
 
 int mic_hip_pics_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) {
+    return mic_hip_pics_decompress_ex(c, len, pixels_out, width, height, nullptr);
+}
+int mic_hip_pics_decompress_ex(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height, int *failed_strip) {
+    if (failed_strip) *failed_strip = -1;
     if (!c || !pixels_out) return MIC_ERR_ARGS;
     mic_hip_pics_dec_job j{};
     j.compressed = c; j.compressed_len = len; j.pixels_out = pixels_out; j.width = width; j.height = height;
     const int rc = mic_hip_pics_decompress_batch(&j, 1);
+    if (rc == MIC_OK && j.status != MIC_OK && failed_strip) *failed_strip = j.failed_strip;
     return rc ? rc : j.status;
 }
 
@@ -578,14 +676,29 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
     const size_t header = 20 + (size_t)nframes * 8;
     if (out_cap < header) return MIC_ERR_CAPACITY;
-    DefaultLease lease;
-    int rc = lease.acquire();
+    int rc = ensure_device();
     if (rc) return rc;
-    std::vector<EncGroup> G(1, EncGroup{ frames, out, out_cap, header, 0, nframes });
-    std::vector<EncUnit> U;
-    for (int i = 0; i < nframes; i++) U.push_back(EncUnit{ (uint64_t)npx * (uint64_t)i, width, height, max_value, 2, 0 });
-    if ((rc = encode_groups(lease.s, G, U))) return rc;
-    if (G[0].status != MIC_OK) return G[0].status;
+    // One group per device: a shard's streams land at a provisional place of the caller's buffer -- where they would start if every
+    // frame before them came out at its bound -- and are moved down behind the shard before once all lengths are known (the frames of
+    // the first shard lie where they belong at once).  That needs the buffer the capacity contract promises; a smaller one: one shard.
+    const size_t fb = MIC_HIP_FRAME_BOUND(npx);
+    int shards = cur_default() ? 1 : (int)std::min<size_t>(default_devices().size(), (size_t)nframes / 8);
+    if (shards < 1 || out_cap < header + (size_t)nframes * fb) shards = 1;
+    std::vector<EncGroup> G; std::vector<EncUnit> U;
+    for (int k = 0; k < shards; k++) {
+        const int f0 = (int)((int64_t)nframes * k / shards), f1 = (int)((int64_t)nframes * (k + 1) / shards);
+        const size_t start = shards == 1 ? header : header + (size_t)f0 * fb;
+        G.push_back(EncGroup{ frames, out, shards == 1 ? out_cap : start + (size_t)(f1 - f0) * fb, start, f0, f1 - f0 });
+        for (int i = f0; i < f1; i++) U.push_back(EncUnit{ (uint64_t)npx * (uint64_t)i, width, height, max_value, 2, k });
+    }
+    if ((rc = encode_sharded(G, U))) return rc;
+    size_t written = 0;
+    for (int k = 0; k < shards; k++) {
+        if (G[(size_t)k].status != MIC_OK) return G[(size_t)k].status;
+        if (k && G[(size_t)k].written) memmove(out + header + written, out + G[(size_t)k].hdr, G[(size_t)k].written);
+        written += G[(size_t)k].written;
+    }
+    G[0].written = written;
     if (G[0].written > 0xFFFFFFFFull) return MIC_ERR_UNSUPPORTED;       // u32 offsets, multiframe.go:75-80
     memset(out, 0, 20);
     memcpy(out, "MIC2", 4);
@@ -612,18 +725,22 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
     if (temporal) return mic2_temporal_decompress(c, len, w, h, n, n, frames_out);   // mic_temporal.hip
     const size_t data_off = 20 + (size_t)n * 8;
-    std::vector<DecGroup> G(1, DecGroup{ c, frames_out, 0, n });
-    std::vector<DecUnit> U;
-    for (int i = 0; i < n; i++) {
-        const size_t start = data_off + get_u32(c + 20 + (size_t)i * 8), bl = get_u32(c + 24 + (size_t)i * 8);
-        if (start + bl > len) return MIC_ERR_CORRUPT;                     // multiframe.go:137-139
-        if (bl == 0) return MIC_ERR_CORRUPT;
-        U.push_back(DecUnit{ start, bl, (uint64_t)npx * (uint64_t)i, w, h, 0, 0 });
+    if ((rc = ensure_device())) return rc;
+    const int shards = cur_default() ? 1 : std::max(1, (int)std::min<size_t>(default_devices().size(), (size_t)n / 8));   // (frames decode into fixed places: any cut will do)
+    std::vector<DecGroup> G; std::vector<DecUnit> U;
+    for (int k = 0; k < shards; k++) {
+        const int f0 = (int)((int64_t)n * k / shards), f1 = (int)((int64_t)n * (k + 1) / shards);
+        G.push_back(DecGroup{ c, frames_out, f0, f1 - f0 });
+        for (int i = f0; i < f1; i++) {
+            const size_t start = data_off + get_u32(c + 20 + (size_t)i * 8), bl = get_u32(c + 24 + (size_t)i * 8);
+            if (start + bl > len) return MIC_ERR_CORRUPT;                 // multiframe.go:137-139
+            if (bl == 0) return MIC_ERR_CORRUPT;
+            U.push_back(DecUnit{ start, bl, (uint64_t)npx * (uint64_t)i, w, h, 0, k });
+        }
     }
-    DefaultLease lease;
-    if ((rc = lease.acquire())) return rc;
-    if ((rc = decode_groups(lease.s, G, U))) return rc;
-    return G[0].status;
+    if ((rc = decode_sharded(G, U))) return rc;
+    for (const DecGroup &g : G) if (g.status != MIC_OK) return g.status;
+    return MIC_OK;
 }
 
 }  // extern "C"

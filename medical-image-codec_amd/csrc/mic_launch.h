@@ -56,7 +56,8 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
 #define MIC_CLS_INTS(n) (MIC_CLS_HEAD + MIC_CLS_CLASSES * (size_t)(n))
 void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t rows_kmask = ~0u);
 void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t);
-void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, hipStream_t stream, MicTimer *t);
+// d_cap: bytes of d_dst -- a batch whose streams do not fit is left alone (dst_off[n], the total, says so)
+void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, uint64_t d_cap, hipStream_t stream, MicTimer *t);
 // rows_kmask: chunk classes of k_dec_predict_rows (mic_decode_rows.hip) the batch can hold -- bit (K - 18) / 4; ~0u when the caller does not know its widths
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false, uint32_t rows_kmask = ~0u);
 void mic_launch_decode_rows(MicUnit *d_units, int n, hipStream_t stream, uint32_t kmask);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <string>
 #include <atomic>
@@ -93,6 +94,21 @@ struct PinnedUnits {
     void release() { if (inflight) (void)hipEventSynchronize(ev); inflight = false; if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
 };
 
+// a small pinned array the device writes results into (offsets of the packed streams)
+struct PinnedU64 {
+    uint64_t *p = nullptr; size_t cap = 0;
+    int reserve(size_t count) {
+        if (count <= cap) return MIC_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = count + count / 4 + 64;
+        HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(uint64_t), hipHostMallocDefault));
+        cap = want;
+        return MIC_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 constexpr size_t kSym = 65536;
 
 // Two tiers of per-unit slabs.  Tier 2 is the worst case: two tokens per pixel (every pixel an escape), a 65536-symbol alphabet,
@@ -133,7 +149,14 @@ struct mic_hip_session {
     DevBuf wsi_planes, wsi_stats, wsi_payload, wsi_recs; std::vector<DevBuf> wsi_pyr;
     PinnedUnits h_units;
     std::vector<uint64_t> h_off;
+    // what an enqueue has already put behind its chain (session_*_finish then only synchronises): the read-back of the descriptors;
+    // for encode also scan + pack into `packed` (capacity pack_cap at that time) and the read-back of the offsets into pin_off
+    bool readback_queued = false, pack_queued = false;
+    size_t pack_cap = 0, pack_hint = 0;           // pack_hint: bytes the session's last batch packed to
+    PinnedU64 pin_off;
     int n_last = 0;
+    // a launch chain over n units has been enqueued; nothing is queued behind it yet (the enqueue that queues its read-back says so after this)
+    void begin_chain(int n) { n_last = n; readback_queued = false; pack_queued = false; }
     int variant = 0;                        // launch flags (MIC_VARIANT_GRAD is OR-ed in per call)
     // The per-unit 65536-bin histograms are ZERO between calls: the encode chain leaves them so (k_enc_hist_clean re-zeroes what a
     // unit's tokeniser counted), and nothing else writes them.  hist_zero_units = leading unit slabs known to be zero (0 after a
@@ -227,7 +250,8 @@ struct mic_hip_session {
         for (DevBuf &b : wsi_pyr) b.release();
         wsi_pyr.clear();
         if (wsi) { mic_wsi_store_free(wsi); wsi = nullptr; }
-        h_units.release();
+        h_units.release(); pin_off.release();
+        readback_queued = pack_queued = false;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         timer.destroy();
@@ -239,13 +263,15 @@ namespace micapi {
 // A session of the default pool, held by the calling thread for the duration of a host-pointer entry point (mic_api.hip).
 struct DefaultLease {
     mic_hip_session *s = nullptr; bool held = false;
-    int acquire();                  // MIC_OK, or why there is no device; blocks while every pooled session is out
+    int acquire(int device = -1);   // MIC_OK, or why there is no device; blocks while every pooled session of the device is out.
+                                    // device: one of mic_hip_set_devices' list (-1: its first -- the default)
     ~DefaultLease();
     DefaultLease() = default;
     DefaultLease(const DefaultLease &) = delete;
     DefaultLease &operator=(const DefaultLease &) = delete;
 };
 mic_hip_session *cur_default();     // the session the calling thread holds
+std::vector<int> default_devices(); // the devices of the host-pointer entry points (mic_hip_set_devices), the default first
 int session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n);
 int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates);
 int session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,

@@ -112,7 +112,7 @@ int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nf
         s->timer.reset(s->stream);
         mic_launch_encode((MicUnit *)s->units.p, nb, s->stream, s->variant, nullptr);
         if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
-        s->n_last = nb;
+        s->begin_chain(nb);
         std::vector<uint64_t> offs((size_t)nb + 1);
         std::vector<int32_t> st((size_t)nb), ns((size_t)nb);
         const uint8_t *d_blobs = nullptr;
@@ -181,7 +181,7 @@ int mic2_temporal_decompress(const uint8_t *c, size_t len, int w, int h, int n_t
             hipLaunchKernelGGL(k_tmp_check, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s->stream, (MicUnit *)s->units.p, nb, (uint32_t)npx, r0);
         }
         HIP_TRY(hipGetLastError());
-        s->n_last = nb;
+        s->begin_chain(nb);
         std::vector<int32_t> st((size_t)nb);
         if ((rc = session_decode_finish(s, st.data()))) return rc;
         for (int i = 0; i < nb; i++) if (st[(size_t)i] != MIC_OK) return st[(size_t)i];

@@ -809,7 +809,7 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     }
     mic_launch_encode((MicUnit *)s->units.p, nf, s->stream, s->variant, &s->timer);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return done(MIC_ERR_DEVICE); }
-    s->n_last = nf;
+    s->begin_chain(nf);
     std::vector<uint64_t> offs((size_t)nf + 1); std::vector<int32_t> ns((size_t)nf); const uint8_t *d_blobs = nullptr;
     st.assign((size_t)nf, 0);
     if ((rc = session_encode_finish(s, &d_blobs, offs.data(), st.data(), ns.data()))) return done(rc);
@@ -873,7 +873,7 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     }
     s->timer.mark("end");
     if (hipGetLastError() != hipSuccess) return done(MIC_ERR_DEVICE);
-    s->n_last = nf;
+    s->begin_chain(nf);
     st.assign((size_t)nf, 0);
     if ((rc = session_decode_finish(s, st.data()))) return done(rc);
     return done(MIC_OK);

@@ -17,10 +17,11 @@ python3 bench.py --no-cpu --no-legs --no-e2e > $OUT/bench_plain.json 2> $OUT/pla
 rocprofv3 --kernel-trace --stats -d $OUT/legs -- python3 bench.py --no-cpu --no-e2e --legs-only > $OUT/bench_legs_trace.json 2> $OUT/legs.err
 LG=$(find $OUT/legs -name "*.db" | head -1)
 python3 - "$LG" $OUT/summary_legs_kernel_stats.csv <<'PY'
-import csv, sqlite3, sys
-rows = sqlite3.connect(sys.argv[1]).cursor().execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
-w = csv.writer(open(sys.argv[2], "w", newline="")); w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us"])
-for n, c, t, a, mi, ma in rows: w.writerow([n, c] + ["%.3f" % (x / 1e3) for x in (t, a, mi, ma)])
+import csv, sys
+sys.path.insert(0, "tools")
+import prof_summary as ps
+w = csv.writer(open(sys.argv[2], "w", newline="")); w.writerow(["kernel", "calls_with_work", "total_us", "avg_us", "min_us", "max_us", "empty_calls_left_out"])
+for r in ps.kernel_stats(sys.argv[1]): w.writerow([r[0], r[1]] + ["%.3f" % x for x in r[2:6]] + [r[6]])
 PY
 T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1); S=$(find $OUT/sq -name "*.db" | head -1)
 echo "dbs: $T $F $W $S"
