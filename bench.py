@@ -19,7 +19,12 @@ legs         = the same measurement for BASELINE configs 3 (WaveletV2 on CR-shap
 batch_sweep  = the headline at B in {1, 64, 288, 512} frames per launch, kernel time.
 cpu_baseline = the reference's own C codec (ojph/mic_compress_c.c + mic_decompress_c.c, built in place into
                oracle/_ref/libmic_ref.so; kind "reference") coding the strips of one of the frames on the host cores, one
-               strip per thread (the mic_parallel.c model); the CPU oracle (kind "port") is timed the same way beside it.
+               strip per thread (the mic_parallel.c model: eight threads), and -- "all_cores" -- as many frames in flight as the
+               host has cores / 8, one strip per thread on every core; "host" names the box (nproc, CPU model); the CPU oracle
+               (kind "port") is timed beside it.
+determinism  = two consecutive encode steps must produce byte-identical streams for every unit (asserted, outside the timed region).
+end_to_end   = host buffers in and out through the C ABI's batch entry points; for N > 1 rank 0 drives all N devices from ONE
+               process (mic_hip_set_devices), which is what a Go host would do: host-path GB/s over 1 / 2 / 4 / 8 PCIe links.
 """
 import argparse
 import importlib
@@ -108,6 +113,73 @@ def cpu_baseline(mico, img, maxv, strips, budget_s=12.0, ref=None):
     return {"value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": cores, "kind": "reference" if ref is not None else "port",
             "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
             "sample": f"{reps} x encode+decode of the {len(parts)} strips of one {w}x{h} frame, {who}, one strip per thread ({cores} threads)"}
+
+
+def host_info():
+    """core count and CPU model of the box the CPU figures come from"""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"nproc": os.cpu_count() or 1, "usable": usable, "model": model}
+
+
+def cpu_all_cores(img, strips, ref, budget_s=8.0):
+    """Every usable core busy, the way a Go host would keep them: cores / strips frames in flight, one strip per thread (the model of
+    ojph/mic_parallel.c:146-181 run from as many goroutines as there are frames).  Reference C codec only."""
+    import ctypes as C
+    h, w = img.shape
+    bounds = pics_strips(w, h, strips)
+    cores = host_info()["usable"]
+    frames = max(1, cores // len(bounds))
+    threads = min(cores, frames * len(bounds))
+    imgs = [img] + [np.ascontiguousarray(np.roll(img, 17 * i, axis=1)) for i in range(1, frames)]     # (own memory per frame in flight)
+    parts = [np.ascontiguousarray(im[a:b]) for im in imgs for a, b in bounds]
+
+    def enc(p):
+        out = np.empty(p.size * 4 + 135168, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = ref.mic_compress_two_state(p.ctypes.data, p.shape[1], p.shape[0], out.ctypes.data, out.size, C.byref(n))
+        assert rc == 0
+        return out[: n.value]
+
+    def dec(args):
+        blob, p = args
+        px = np.empty_like(p)
+        rc = ref.mic_decompress_two_state_simd(blob.ctypes.data, blob.size, px.ctypes.data, p.shape[1], p.shape[0])
+        assert rc == 0
+        return 0
+
+    reps, t_enc, t_dec = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        while reps < 1 or (time.perf_counter() - t_start) < budget_s:
+            t0 = time.perf_counter(); blobs = list(ex.map(enc, parts)); t1 = time.perf_counter()
+            list(ex.map(dec, zip(blobs, parts))); t2 = time.perf_counter()
+            t_enc += t1 - t0; t_dec += t2 - t1; reps += 1
+    raw = img.nbytes * frames * reps
+    return {"value": raw / (t_enc + t_dec) / 1e9, "unit": "GB/s", "cores": threads, "frames_in_flight": frames,
+            "encode_GBps": raw / t_enc / 1e9, "decode_GBps": raw / t_dec / 1e9,
+            "sample": f"{reps} x encode+decode of {frames} frames x {len(bounds)} strips, reference C codec, one strip per thread on {threads} threads"}
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: a profile's counters describe the build they were taken on, and no other"""
+    import hashlib
+    d = os.path.join(ROOT, "medical-image-codec_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode()); hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def roofline_block(kmean, raw_bytes, comp_bytes, traffic=None):
@@ -374,14 +446,20 @@ def legs_multi_gpu(mic, torch, synth, par, dist, dev, rank, world, steps=5):
     return out
 
 
-def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
+def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev, devices=None):
     """SURVEY.md §8(d) "Timing", the second figure: host buffers in, host buffers out, through the C ABI's batch entry points
     (mic_hip_pics_compress_batch / _decompress_batch -- what a cgo caller uses), for ordinary (pageable) numpy buffers and for
     pinned ones (mic_hip_host_alloc), at B = all frames and B = 1; beside it the box's pinned H2D / D2H copy rates, and the
     fraction of the PCIe floor (bytes in / H2D rate + bytes out / D2H rate) the call reaches."""
-    B = d_px.shape[0]
+    B0 = d_px.shape[0]
     frame_bytes = W * H * 2
-    host = d_px.cpu().numpy().view(np.uint16).reshape(B, H, W)
+    host0 = d_px.cpu().numpy().view(np.uint16).reshape(B0, H, W)
+    # several devices (ONE process, mic_hip_set_devices): the batch is B0 frames per device -- the same frames for every device, which
+    # costs the host no memory and the codec nothing -- so that every link carries what the single link carries at N = 1
+    ndev = len(devices) if devices else 1
+    B = B0 * ndev
+    if devices:
+        mic.set_devices(devices)
 
     # the link: one 1 GiB pinned buffer each way
     n = 1 << 30
@@ -399,15 +477,15 @@ def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
 
     def run(kind):
         if kind == "pinned":
-            src = mic.host_alloc(B * frame_bytes, np.uint16).reshape(B, H, W)
-            src[...] = host
+            src = mic.host_alloc(B0 * frame_bytes, np.uint16).reshape(B0, H, W)
+            src[...] = host0
             cbuf = mic.host_alloc(B * frame_bytes)
             back = mic.host_alloc(B * frame_bytes, np.uint16).reshape(B, H, W)
         else:
-            src = host
+            src = host0
             cbuf = np.empty(B * frame_bytes, dtype=np.uint8)
             back = np.empty((B, H, W), dtype=np.uint16)
-        imgs = [src[i] for i in range(B)]
+        imgs = [src[i % B0] for i in range(B)]
         outs = [cbuf[i * frame_bytes:(i + 1) * frame_bytes] for i in range(B)]
         pxo = [back[i].reshape(-1) for i in range(B)]
         best = None
@@ -423,7 +501,8 @@ def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
             assert all(st == 0 for st, _ in dec)
             if it and (best is None or (t1 - t0) + (t3 - t2) < best[0] + best[1]):
                 best = (t1 - t0, t3 - t2)
-        assert np.array_equal(back, host), "end-to-end round trip differs"
+        for k in range(ndev):
+            assert np.array_equal(back[k * B0:(k + 1) * B0], host0), "end-to-end round trip differs"
         comp = sum(len(f) for f in files)
         raw = B * frame_bytes
         floor_enc = raw / rates["h2d"] / 1e9 + comp / rates["d2h"] / 1e9
@@ -446,8 +525,14 @@ def leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev):
         return r
 
     out = {"what": f"mic_hip_pics_compress_batch + mic_hip_pics_decompress_batch, {B} frames ({B * S} strips) per call, host buffers in and out",
+           "devices": list(devices) if devices else [dev.index if dev.index is not None else 0], "process": "one",
            "pcie_pinned_GBps": {k: round(v, 2) for k, v in rates.items()},
-           "pageable": run("pageable"), "pinned": run("pinned")}
+           "pcie_note": "link rates and floors are ONE device's; with N devices the floor of the call is that of a 1 / N share",
+           "pageable": run("pageable")}
+    if ndev == 1:
+        out["pinned"] = run("pinned")
+    if devices:
+        mic.set_devices([devices[0]])
     return out
 
 
@@ -543,15 +628,36 @@ def main():
 
         assert torch.equal(d_out, d_px), "round trip differs"             # lossless check of the last step (outside the timed region)
         comp_bytes = int(offs[-1])
+        # consecutive steps, byte for byte: a lossless codec's stream is a pure function of its input (fse2state.go:122-199,
+        # fsecompressu16.go:81-187) -- every unit's bytes and every offset of the next steps equal this one's (outside the timed region)
+        first = torch.empty(comp_bytes, dtype=torch.uint8, device=dev)
+        mic.device_copy(first.data_ptr(), d_blobs, comp_bytes)
+        offs_first = np.array(offs, copy=True)
+        same_all = True
+        for _ in range(2):
+            d_blobs2, offs2, _ = step()
+            again = torch.empty(int(offs2[-1]), dtype=torch.uint8, device=dev)
+            mic.device_copy(again.data_ptr(), d_blobs2, int(offs2[-1]))
+            same_all = same_all and np.array_equal(offs2, offs_first) and bool(torch.equal(again, first))
+            del again
+        assert same_all, "the encoder produced different bytes for the same input in consecutive steps"
+        determinism = {"steps_compared": 3, "units": n_units, "bytes": comp_bytes, "identical": True}
+        del first
         raw_bytes = d_px.numel() * 2
         kmean = mean_timings([step(True)[2] for _ in range(3)])           # per-kernel device times, separate instrumented steps
         dom = max(kmean, key=kmean.get)
-        traffic = None                                                    # HBM bytes of the dominant kernel from the committed PMC passes (same command)
+        # HBM bytes of the dominant kernel: the committed PMC passes of this same command (tools/profile_bench.sh) -- used only when
+        # they were taken on THIS build of the kernels (the profile records a hash of csrc/) and on this workload
+        traffic, traffic_source = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+            meta = tj.get("_meta", {})
             ent = tj.get(dom)
-            if ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
+            if meta.get("csrc_sha16") != csrc_fingerprint():
+                traffic_source = {"file": "profiles/r04_traffic.json", "used": False, "why": "csrc/ changed since the profile was taken"}
+            elif ent and ent.get("frames_per_gpu") == B and ent.get("width") == W and ent.get("height") == H and ent.get("depth") == args.depth:
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = {"file": "profiles/r04_traffic.json", "used": True, "csrc_sha16": meta.get("csrc_sha16")}
         except Exception:
             traffic = None
         ms_step = elapsed / args.steps * 1e3
@@ -588,6 +694,8 @@ def main():
             "decode_GBps_kernels": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 4) if dec_ms else None,
             "kernel_ms": {k: round(v, 4) for k, v in kmean.items() if v >= 0.02},
             "roofline": roofline_block(kmean, raw_bytes, comp_bytes, traffic),
+            "traffic_source": traffic_source,
+            "determinism": determinism,
             "container_assembly": assembly,
             "workspace": {"session_bytes": sess.workspace_bytes()[0], "tier2": sess.workspace_bytes()[1],
                           "x_input": round(sess.workspace_bytes()[0] / raw_bytes, 2)},
@@ -610,6 +718,18 @@ def main():
 
     if world == 1 and not args.no_e2e and not args.legs_only:
         out["end_to_end"] = leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev)
+        torch.cuda.empty_cache()
+    if world > 1 and not args.no_e2e and not args.legs_only:
+        # ONE process, all N devices (what a Go host does): rank 0 drives every GPU of the job through mic_hip_set_devices while the
+        # other ranks wait at the barrier below with their sessions closed
+        torch.cuda.empty_cache()
+        dist.barrier()
+        if rank == 0:
+            try:
+                out["end_to_end"] = leg_end_to_end(mic, torch, d_px, W, H, S, maxv, dev, devices=list(range(world)))
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end"] = {"error": repr(e)}
+        dist.barrier()
         torch.cuda.empty_cache()
 
     if world == 1 and not args.no_legs:
@@ -654,25 +774,27 @@ def main():
         frame0 = synth.xr_like(cols=W, rows=H, depth=args.depth, seed=seed0, noise=noise)      # == frame 0 of the device batch
         port = cpu_baseline(mico, frame0, maxv, S, budget_s=8.0)
         if ref is not None:
-            out["cpu_baseline"] = cpu_baseline(mico, frame0, maxv, S, budget_s=10.0, ref=ref)
+            out["cpu_baseline"] = cpu_baseline(mico, frame0, maxv, S, budget_s=8.0, ref=ref)
             out["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "encode_GBps", "decode_GBps", "cores")}
+            out["cpu_baseline"]["all_cores"] = cpu_all_cores(frame0, S, ref, budget_s=8.0)
         else:
             out["cpu_baseline"] = port
+        out["cpu_baseline"]["host"] = host_info()
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and out.get("cpu_baseline") and out.get("batch_sweep"):
         # smallest batch at which the device (frames resident in HBM) outruns this box's host cores on the same frames
-        cpu = out["cpu_baseline"]["value"]
         sw = out["batch_sweep"]
-        cross = None
-        for a, b in zip(sw, sw[1:]):
-            if a["GBps"] < cpu <= b["GBps"]:
-                f = (cpu - a["GBps"]) / (b["GBps"] - a["GBps"])
-                cross = int(np.ceil(a["frames"] + f * (b["frames"] - a["frames"])))
-                break
-        if cross is None and sw[0]["GBps"] >= cpu:
-            cross = sw[0]["frames"]
-        out["crossover_frames"] = cross
+
+        def crossover(cpu):
+            for a, b in zip(sw, sw[1:]):
+                if a["GBps"] < cpu <= b["GBps"]:
+                    f = (cpu - a["GBps"]) / (b["GBps"] - a["GBps"])
+                    return int(np.ceil(a["frames"] + f * (b["frames"] - a["frames"])))
+            return sw[0]["frames"] if sw[0]["GBps"] >= cpu else None
+        ac = out["cpu_baseline"].get("all_cores")
+        out["crossover_frames"] = crossover(ac["value"] if ac else out["cpu_baseline"]["value"])       # vs every core of the host
+        out["crossover_frames_8_threads"] = crossover(out["cpu_baseline"]["value"])                    # vs one frame's eight strips
     if dist is not None:
         dist.barrier()
     sys.stdout.flush()

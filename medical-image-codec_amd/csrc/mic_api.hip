@@ -134,7 +134,9 @@ static int encode_enqueue_tier(mic_hip_session *s, const uint16_t *d_pixels, con
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(n))) return rc;
     s->timer.reset(s->stream);
-    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0) | (narrow ? MIC_VARIANT_NARROW : 0), &s->timer);
+    mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | MIC_VARIANT_FRAMES | (any_grad ? MIC_VARIANT_GRAD : 0) | (narrow ? MIC_VARIANT_NARROW : 0), &s->timer,
+                      s->enc_classes.mask());
+    s->learn_encode = true;
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->begin_chain(n);
     // Compaction and the read-back of the results ride behind the chain, so that session_encode_finish is ONE synchronisation (round 3:
@@ -196,10 +198,40 @@ static int finish_units(mic_hip_session *s, int n) {
     return MIC_OK;
 }
 
+// what the batch just finished tells the next one (mic_launch.h: launch masks)
+static void learn_classes(mic_hip_session *s, int n) {
+    if (s->learn_decode) {
+        uint32_t seen = 0;
+        for (int i = 0; i < n; i++) {
+            const MicUnit &u = s->h_units[(size_t)i];
+            const int c = mic_dec_cls(u.flavour, u.table_log, u.zero_bits);
+            if (c >= 0 && u.comp_len - u.bits_off < (1u << 27)) seen |= 1u << c;
+        }
+        s->dec_classes.learn(seen);
+    }
+    if (s->learn_encode) {
+        uint32_t seen = 0;
+        for (int i = 0; i < n; i++) {
+            const MicUnit &u = s->h_units[(size_t)i];
+            const uint32_t tl = u.table_log;
+            if (tl < MIC_MIN_TABLELOG || tl > MIC_MAX_TABLELOG) continue;                 // (the chain stopped in front of the tANS stage)
+            if (tl == 14) seen |= MIC_ENC_CLS_TL14;
+            else if (tl == 15) seen |= MIC_ENC_CLS_TL15;
+            else if (tl == 16) seen |= MIC_ENC_CLS_TL16;
+            else if (u.ntok <= 98304u && u.symbol_len <= 1024u) seen |= (tl <= 12 && u.symbol_len <= 512u) ? MIC_ENC_CLS_SMALL12 : MIC_ENC_CLS_SMALL13;   // te_small_class, mic_encode.hip
+            else if (u.nstates == 2 && u.symbol_len <= 4096u) seen |= MIC_ENC_CLS_NARROW2 | (u.nstates_used != 2 ? MIC_ENC_CLS_WIDE : 0u);
+            else seen |= MIC_ENC_CLS_WIDE;
+        }
+        s->enc_classes.learn(seen);
+    }
+    s->learn_decode = s->learn_encode = false;
+}
+
 int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
     int n = s->n_last;
     if (n <= 0) return MIC_ERR_ARGS;
     { const int frc = finish_units(s, n); if (frc) return frc; }
+    learn_classes(s, n);
     uint64_t total = 0;
     for (int i = 0; i < n; i++) {
         const MicUnit &u = s->h_units[(size_t)i];
@@ -253,10 +285,10 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     if (rc) return rc;
     { const int arc = s->h_units.assign((size_t)n, MicUnit{}); if (arc) return arc; }
     bool any_grad = false;
-    uint32_t rows_kmask = 0;                                             // chunk classes of the row-by-row predictor this batch holds
+    uint32_t rows_kmask = 0;                                             // predictor classes (by width) this batch holds
     for (int i = 0; i < n; i++) {
         MicUnit &u = s->h_units[(size_t)i];
-        rows_kmask |= mic_rows_kbit(units[i].width);
+        rows_kmask |= mic_pred_bit(units[i].width);
         const uint64_t len = ends[i] - begins[i];
         u.comp_in = d_blobs + begins[i]; u.comp_len = (uint32_t)len;
         u.px_out = d_pixels_out + units[i].px_offset;
@@ -269,7 +301,9 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     HIP_TRY(hipMemsetAsync(s->flags.p, 0, s->flag_stride * (size_t)n, s->stream));
     s->timer.reset(s->stream);
-    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p, rows_kmask);
+    mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p, rows_kmask,
+                      s->dec_classes.mask());
+    s->learn_decode = true;
     HIP_TRY(hipGetLastError());
     s->begin_chain(n);
     HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
@@ -281,6 +315,7 @@ int session_decode_finish(mic_hip_session *s, int32_t *h_status) {
     int n = s->n_last;
     if (n <= 0) return MIC_ERR_ARGS;
     { const int frc = finish_units(s, n); if (frc) return frc; }
+    learn_classes(s, n);
     for (int i = 0; i < n; i++) h_status[i] = s->h_units[(size_t)i].status;
     return MIC_OK;
 }

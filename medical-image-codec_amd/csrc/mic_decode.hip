@@ -271,13 +271,13 @@ __global__ void __launch_bounds__(64) k_dec_tans_gl(MicUnit *units) {
 }
 
 
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t rows_kmask) {
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t pred_mask, uint32_t cls_mask) {
     const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
     if (t) t->mark("k_dec_tables_wg");
     mic_launch_dec_tables(d_units, n, stream);
     // lane-per-state kernels over compacted per-class lists (mic_decode_ls.hip): every table size has its class; what they leave
     // (a tableLog-16 table with 0-bit entries, 1-state streams) falls through to the kernels below, which skip decoded units
-    mic_launch_dec_tans_ls(d_units, n, d_cls + MIC_CLS_HEAD, d_cls, stream, t);
+    mic_launch_dec_tans_ls(d_units, n, d_cls + MIC_CLS_HEAD, d_cls, stream, t, cls_mask);
     if (t) t->mark("k_dec_tans_gl<2>");
     hipLaunchKernelGGL(k_dec_tans_gl<2>, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_dec_tans_gl<4,8>");
@@ -285,6 +285,6 @@ void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     hipLaunchKernelGGL(k_dec_tans_gl<8>, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_dec_tans_serial");
     hipLaunchKernelGGL(k_dec_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
-    mic_launch_decode_pixels(d_units, n, stream, t, any_grad, rows_kmask);
+    mic_launch_decode_pixels(d_units, n, stream, t, any_grad, pred_mask);
     if (t) t->mark("end");
 }

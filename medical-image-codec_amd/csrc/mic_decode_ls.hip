@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_dec_classify(MicUnit *units, int n, in
                 if (u.bits_off >= u.comp_len) u.status = MICD_ERR_CORRUPT;
                 else if (u.comp_len - u.bits_off < (1u << 27)) {            // 32-bit bit positions here; the serial kernel takes longer ones
                     if (u.comp_in[u.comp_len - 1] == 0) u.status = MICD_ERR_CORRUPT;
-                    else cls = (tl <= 12 ? 4 : (int)tl - 13) * 6 + (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (u.zero_bits ? 1 : 0);
+                    else cls = mic_dec_cls(flav, tl, u.zero_bits);
                 }
             }
         }
@@ -665,8 +665,9 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
 }
 
 template <int N, bool ZB, int TL>
-static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream) {
+static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream, uint32_t cls_mask) {
     constexpr int cls = (TL <= 12 ? 4 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
+    if (!((cls_mask >> cls) & 1u)) return;                                  // (the session has not seen a stream of this class lately: mic_launch.h)
     constexpr int per = LsGeom<TL>::WAVES * LsGeom<TL>::SPW;
     static MicPerDeviceOnce once;
     once.run([] { (void)hipFuncSetAttribute((const void *)k_dec_tans_ls<N, ZB, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, LsGeom<TL>::LDS); });
@@ -675,30 +676,31 @@ static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const in
                        d_list + (size_t)cls * (size_t)n, d_count + cls);
 }
 template <int TL>
-static void launch_ls_tl(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream, bool skip_first) {
-    if (!skip_first) launch_ls_class<2, false, TL>(d_units, n, d_list, d_count, stream);
-    if constexpr (TL < 16) launch_ls_class<2, true, TL>(d_units, n, d_list, d_count, stream);
-    launch_ls_class<4, false, TL>(d_units, n, d_list, d_count, stream);
-    if constexpr (TL < 16) launch_ls_class<4, true, TL>(d_units, n, d_list, d_count, stream);
-    launch_ls_class<8, false, TL>(d_units, n, d_list, d_count, stream);
-    if constexpr (TL < 16) launch_ls_class<8, true, TL>(d_units, n, d_list, d_count, stream);
+static void launch_ls_tl(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream, bool skip_first, uint32_t m) {
+    if (!skip_first) launch_ls_class<2, false, TL>(d_units, n, d_list, d_count, stream, m);
+    if constexpr (TL < 16) launch_ls_class<2, true, TL>(d_units, n, d_list, d_count, stream, m);
+    launch_ls_class<4, false, TL>(d_units, n, d_list, d_count, stream, m);
+    if constexpr (TL < 16) launch_ls_class<4, true, TL>(d_units, n, d_list, d_count, stream, m);
+    launch_ls_class<8, false, TL>(d_units, n, d_list, d_count, stream, m);
+    if constexpr (TL < 16) launch_ls_class<8, true, TL>(d_units, n, d_list, d_count, stream, m);
 }
 
 // d_list: LS_CLASSES * n ints, d_count: LS_CLASSES ints (session workspace)
-void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t) {
+void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t, uint32_t cls_mask) {
     if (t) t->mark("k_dec_classify");
     hipLaunchKernelGGL(k_dec_classify, dim3(1), dim3(1024), 0, stream, d_units, n, d_list, d_count);
     if (t) t->mark("k_dec_tans_ls<2,false,13>");
-    launch_ls_class<2, false, 13>(d_units, n, d_list, d_count, stream);
+    launch_ls_class<2, false, 13>(d_units, n, d_list, d_count, stream, cls_mask);
     if (t) t->mark("k_dec_tans_ls<other,13>");
-    launch_ls_tl<13>(d_units, n, d_list, d_count, stream, true);
+    launch_ls_tl<13>(d_units, n, d_list, d_count, stream, true, cls_mask);
     if (t) t->mark("k_dec_tans_ls<..12>");
-    launch_ls_tl<12>(d_units, n, d_list, d_count, stream, false);
+    launch_ls_tl<12>(d_units, n, d_list, d_count, stream, false, cls_mask);
     if (t) t->mark("k_dec_tans_ls<14..16>");
-    launch_ls_tl<14>(d_units, n, d_list, d_count, stream, false);
-    launch_ls_tl<15>(d_units, n, d_list, d_count, stream, false);
-    launch_ls_tl<16>(d_units, n, d_list, d_count, stream, false);
+    launch_ls_tl<14>(d_units, n, d_list, d_count, stream, false, cls_mask);
+    launch_ls_tl<15>(d_units, n, d_list, d_count, stream, false, cls_mask);
+    launch_ls_tl<16>(d_units, n, d_list, d_count, stream, false, cls_mask);
     if (t) t->mark("k_dec_translate");
-    hipLaunchKernelGGL(k_dec_translate<13>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
-    hipLaunchKernelGGL(k_dec_translate<16>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    // classes 0-5: tableLog 13, 24-29: tableLog <= 12 -> the 16 KiB symbol table; 6-23: tableLog 14..16 -> the 128 KiB one
+    if (cls_mask & 0x3F00003Fu) hipLaunchKernelGGL(k_dec_translate<13>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    if (cls_mask & 0x00FFFFC0u) hipLaunchKernelGGL(k_dec_translate<16>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
 }

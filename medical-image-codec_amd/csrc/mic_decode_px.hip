@@ -977,26 +977,29 @@ __global__ void __launch_bounds__(64) k_dec_predict_grad(MicUnit *units, int w_l
     }
 }
 
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad, uint32_t rows_kmask) {
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad, uint32_t pred_mask) {
     if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
     // row-buffer classes so that ordinary widths keep many waves per CU: a row buffer is 2 bytes per column and unit, four units per
     // group; up to 4032 columns that is 8 KiB per unit and twenty units per CU (a latency-bound kernel: one wave per unit)
     if (t) t->mark("k_dec_predict<0>");
-    hipLaunchKernelGGL((k_dec_predict<0, 16>), dim3((n + 3) / 4), dim3(256), 4 * 1024 * 2, stream, d_units, n, 0, PR_NARROW, 512u);   // narrow frames: 16-pixel groups (8-pixel groups: slower)
+    if (pred_mask & MIC_PRED_NARROW)
+        hipLaunchKernelGGL((k_dec_predict<0, 16>), dim3((n + 3) / 4), dim3(256), 4 * 1024 * 2, stream, d_units, n, 0, PR_NARROW, 512u);   // narrow frames: 16-pixel groups (8-pixel groups: slower)
     // frames of 1009 .. 2688 columns: row by row, the lanes side by side in a row (k_dec_predict_rows, mic_decode_rows.hip)
     static_assert(PR_NARROW == MIC_ROWS_LO, "the narrow class ends where the row-by-row class begins");
     if (t) t->mark("k_dec_predict_rows");
 #ifdef MIC_PREDICT2_ALL      // (A / B builds: the two-wave wavefront kernel of round 3 for those widths too)
     hipLaunchKernelGGL(k_dec_predict2, dim3(n), dim3(128), (1344u + 2 * P2_TILE + 128) * 4, stream, d_units, PR_NARROW, MIC_ROWS_HI, 1344u);
 #else
-    mic_launch_decode_rows(d_units, n, stream, rows_kmask);
+    mic_launch_decode_rows(d_units, n, stream, pred_mask & 0x7Fu);
 #endif
     // wider frames: two waves per unit (k_dec_predict2: a mover wave and a computing wave over a 64-row band, 16 KiB of row buffer)
     if (t) t->mark("k_dec_predict2");
-    hipLaunchKernelGGL(k_dec_predict2, dim3(n), dim3(128), (4096u + 2 * P2_TILE + 128) * 4, stream, d_units, MIC_ROWS_HI, 8192 - PR_K, 4096u);
+    if (pred_mask & MIC_PRED_WAVE2)
+        hipLaunchKernelGGL(k_dec_predict2, dim3(n), dim3(128), (4096u + 2 * P2_TILE + 128) * 4, stream, d_units, MIC_ROWS_HI, 8192 - PR_K, 4096u);
     if (t) t->mark("k_dec_predict<wide>");
-    hipLaunchKernelGGL((k_dec_predict<1, 64>), dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
+    if (pred_mask & MIC_PRED_WIDE)
+        hipLaunchKernelGGL((k_dec_predict<1, 64>), dim3(n), dim3(64), (PR_MAX_W + PR_K) * 2, stream, d_units, n, 8192 - PR_K, PR_MAX_W, 0u);
     if (any_grad) {
         if (t) t->mark("k_dec_predict_grad");
         static MicPerDeviceOnce once;

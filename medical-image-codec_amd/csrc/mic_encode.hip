@@ -1330,13 +1330,13 @@ __global__ void __launch_bounds__(256) k_enc_hist_clean(MicUnit *units) {
 
 // ------------------------------------------------------------------------------------------
 // launchers
-void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t) {
-    const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0;
+void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, uint32_t enc_mask) {
+    const bool any_grad = (variant & MIC_VARIANT_GRAD) != 0, frames = (variant & MIC_VARIANT_FRAMES) != 0;
     if (t) t->mark("k_enc_symbols");
-    hipLaunchKernelGGL(k_enc_symbols, dim3(64, n), dim3(256), 0, stream, d_units);
+    if (!frames) hipLaunchKernelGGL(k_enc_symbols, dim3(64, n), dim3(256), 0, stream, d_units);
     if (t) t->mark("k_enc_tokens_wg");
     hipLaunchKernelGGL(k_enc_tokens_wg<0>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
-    hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
+    if (!frames) hipLaunchKernelGGL(k_enc_tokens_wg<1>, dim3(n), dim3(TK_THREADS), 0, stream, d_units);
     if (any_grad) hipLaunchKernelGGL((k_enc_tokens_wg<0, 1>), dim3(n), dim3(TK_THREADS), 0, stream, d_units);
     if (t) t->mark("k_enc_tables_wg");
     mic_launch_enc_tables(d_units, n, stream);
@@ -1351,15 +1351,16 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     const int es = (variant & MIC_VARIANT_NARROW) ? 2 : 8;                      // widest flavour in the batch -> end-state area
     const unsigned eb = TE_THREADS * (unsigned)es * 2u, eb1 = 64u * (unsigned)es * 2u;
     if (t) t->mark("k_enc_tans_wg<13>");
-    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 1>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + TE_THREADS * 2u * 2u, stream, d_units, 2);
-    hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 2>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    // (classes the session has not seen lately are not launched; k_enc_tans_serial below takes whatever that leaves: mic_launch.h)
+    if (enc_mask & MIC_ENC_CLS_NARROW2) hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 1>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + TE_THREADS * 2u * 2u, stream, d_units, 2);
+    if (enc_mask & MIC_ENC_CLS_WIDE) hipLaunchKernelGGL((k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 2>), dim3(n), dim3(TE_THREADS), (2u << 13) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
     if (t) t->mark("k_enc_tans_wg<13, one wave>");
-    hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8 + eb1, stream, d_units, es);
-    hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8 + eb1, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_SMALL12) hipLaunchKernelGGL((k_enc_tans_wg<12, 64, 512>), dim3(n), dim3(64), (2u << 12) + 512 * 8 + eb1, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_SMALL13) hipLaunchKernelGGL((k_enc_tans_wg<13, 64, TE_SMALL_SYMS>), dim3(n), dim3(64), (2u << 13) + TE_SMALL_SYMS * 8 + eb1, stream, d_units, es);
     if (t) t->mark("k_enc_tans_wg<other classes>");
-    hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
-    hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
-    hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 16) + eb, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_TL14) hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_TL15) hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_TL16) hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 16) + eb, stream, d_units, es);
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_enc_hist_clean");

@@ -49,17 +49,35 @@ struct MicTimer {
 // variant: launch flags -- MIC_VARIANT_GRAD when some unit has pred = 1 (their tokeniser / predictor instantiations are only launched then)
 #define MIC_VARIANT_GRAD 0x1000
 #define MIC_VARIANT_NARROW 0x2000       // encode: no unit of the batch asks for more than two states (sizes k_enc_tans_wg's end-state area)
-void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t);
+#define MIC_VARIANT_FRAMES 0x4000       // encode: every unit is a frame (mode 0, avg or gradient predictor): the symbol-unit kernels are not launched
+// Launch masks.  Most kernels of a chain come in classes (table size, flavour, frame width) and a homogeneous batch uses one or two
+// of them; a launch of a class without units is an empty grid that still costs ~5 us of the device's time (~45 of them per encode +
+// decode of a PICS batch, 0.2 ms).  What the HOST knows (widths, modes) it says outright; what only the streams know (flavour,
+// tableLog) a session remembers from its last batches -- the catch-all kernels (k_dec_tans_gl / _serial, k_enc_tans_serial) are
+// always launched and take whatever a stale mask leaves, so a wrong guess costs time, never correctness.  All ones: launch everything.
+#define MIC_ENC_CLS_NARROW2 0x01u       // k_enc_tans_wg<13, 512, .., 1>: two states, records in LDS
+#define MIC_ENC_CLS_WIDE    0x02u       // k_enc_tans_wg<13, 512, .., 2>
+#define MIC_ENC_CLS_SMALL12 0x04u       // one-wave instances
+#define MIC_ENC_CLS_SMALL13 0x08u
+#define MIC_ENC_CLS_TL14    0x10u
+#define MIC_ENC_CLS_TL15    0x20u
+#define MIC_ENC_CLS_TL16    0x40u
+void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, uint32_t enc_mask = ~0u);
 // d_cls: per-session scratch of MIC_CLS_INTS(n) ints for the per-class unit lists of the lane-per-state tANS decoder (mic_decode_ls.hip)
 #define MIC_CLS_HEAD 32
 #define MIC_CLS_CLASSES 30
 #define MIC_CLS_INTS(n) (MIC_CLS_HEAD + MIC_CLS_CLASSES * (size_t)(n))
-void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t rows_kmask = ~0u);
-void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t);
+// pred_mask: predictor classes by frame width (mic_pred_bit); cls_mask: bit c = lane-per-state class c of mic_decode_ls.hip (MIC_CLS_CLASSES of them)
+void mic_launch_decode(MicUnit *d_units, int n, hipStream_t stream, int variant, MicTimer *t, int *d_cls, uint32_t pred_mask = ~0u, uint32_t cls_mask = ~0u);
+void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, hipStream_t stream, MicTimer *t, uint32_t cls_mask = ~0u);
 // d_cap: bytes of d_dst -- a batch whose streams do not fit is left alone (dst_off[n], the total, says so)
 void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_dst, uint64_t d_cap, hipStream_t stream, MicTimer *t);
-// rows_kmask: chunk classes of k_dec_predict_rows (mic_decode_rows.hip) the batch can hold -- bit (K - 18) / 4; ~0u when the caller does not know its widths
-void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false, uint32_t rows_kmask = ~0u);
+// pred_mask: the predictor kernels the batch's widths call for (mic_pred_bit) -- bits 0..6 the chunk classes of k_dec_predict_rows
+// (bit (K - 18) / 4), MIC_PRED_* the others; ~0u when the caller does not know its widths
+#define MIC_PRED_NARROW 0x100u          // k_dec_predict<0, 16>: up to MIC_ROWS_LO columns
+#define MIC_PRED_WAVE2  0x200u          // k_dec_predict2: MIC_ROWS_HI < columns <= 8128
+#define MIC_PRED_WIDE   0x400u          // k_dec_predict<1, 64>: wider
+void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false, uint32_t pred_mask = ~0u);
 void mic_launch_decode_rows(MicUnit *d_units, int n, hipStream_t stream, uint32_t kmask);
 // Frames of MIC_ROWS_LO < columns <= MIC_ROWS_HI take the row-by-row predictor: pixels per lane and row (0: another kernel's frame)
 #define MIC_ROWS_LO 1008
@@ -70,5 +88,14 @@ __host__ __device__ inline int mic_rows_k(int w) {
     return 18 + 4 * ((max(k, 18) - 18 + 3) / 4);
 }
 __host__ __device__ inline uint32_t mic_rows_kbit(int w) { const int k = mic_rows_k(w); return k ? 1u << ((k - 18) / 4) : 0u; }
+__host__ __device__ inline uint32_t mic_pred_bit(int w) {
+    return w <= MIC_ROWS_LO ? MIC_PRED_NARROW : w <= MIC_ROWS_HI ? mic_rows_kbit(w) : w <= 8192 - 64 ? MIC_PRED_WAVE2 : MIC_PRED_WIDE;
+}
+// lane-per-state decode class of a stream (mic_decode_ls.hip: k_dec_classify), -1: left to k_dec_tans_gl / k_dec_tans_serial
+__host__ __device__ inline int mic_dec_cls(uint32_t flavour, uint32_t tl, uint32_t zero_bits) {
+    const uint32_t ns = flavour == 108 ? 8u : flavour;
+    if (!(ns == 2 || ns == 4 || ns == 8) || tl < MIC_MIN_TABLELOG || tl > MIC_MAX_TABLELOG || (tl == 16 && zero_bits)) return -1;
+    return (tl <= 12 ? 4 : (int)tl - 13) * 6 + (ns == 2 ? 0 : ns == 4 ? 2 : 4) + (zero_bits ? 1 : 0);
+}
 void mic_launch_enc_tables(MicUnit *d_units, int n, hipStream_t stream);
 void mic_launch_dec_tables(MicUnit *d_units, int n, hipStream_t stream);

@@ -156,8 +156,18 @@ struct mic_hip_session {
     PinnedU64 pin_off;
     int n_last = 0;
     // a launch chain over n units has been enqueued; nothing is queued behind it yet (the enqueue that queues its read-back says so after this)
-    void begin_chain(int n) { n_last = n; readback_queued = false; pack_queued = false; }
+    void begin_chain(int n) { n_last = n; readback_queued = false; pack_queued = false; learn_decode = learn_encode = false; }
+    bool learn_decode = false, learn_encode = false;   // the chain in flight was launched under the session's class masks: finish updates them
     int variant = 0;                        // launch flags (MIC_VARIANT_GRAD is OR-ed in per call)
+    // Kernel classes this session's last batches used (mic_launch.h: launch masks): age[c] = batches since class c was last seen;
+    // a class is launched while its age is below kClsKeep.  Nothing seen yet: everything is launched.
+    static constexpr uint8_t kClsKeep = 8;
+    struct ClsMemory {
+        uint8_t age[32]; bool any = false;
+        ClsMemory() { for (uint8_t &a : age) a = 255; }
+        uint32_t mask() const { if (!any) return ~0u; uint32_t m = 0; for (int c = 0; c < 32; c++) if (age[c] < kClsKeep) m |= 1u << c; return m; }
+        void learn(uint32_t seen) { any = true; for (int c = 0; c < 32; c++) age[c] = ((seen >> c) & 1u) ? 0 : (uint8_t)std::min<int>(age[c] + 1, 255); }
+    } dec_classes, enc_classes;
     // The per-unit 65536-bin histograms are ZERO between calls: the encode chain leaves them so (k_enc_hist_clean re-zeroes what a
     // unit's tokeniser counted), and nothing else writes them.  hist_zero_units = leading unit slabs known to be zero (0 after a
     // reallocation, after a failed launch).  The invariant is tied to the ALLOCATION (DevBuf::gen),

@@ -101,6 +101,14 @@ def main():
             "frames_per_gpu": cfg["frames_per_gpu"], "width": cfg["width"], "height": cfg["height"],
             "depth": cfg["max_value"].bit_length(),
             "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, mean over the dispatches that did work; gfx950 FETCH_SIZE counts 128-byte reads as 64"}
+    # the build these counters belong to: bench.py looks a kernel's traffic up here only while csrc/ still hashes to this
+    import hashlib, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "medical-image-codec_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode()); hsh.update(open(os.path.join(d, name), "rb").read())
+    out["_meta"] = {"csrc_sha16": hsh.hexdigest()[:16]}
     json.dump(out, open(prefix + "_traffic.json", "w"), indent=1)
     for r in ks[:14]: print(f"{r[3]:10.1f} us avg  x{r[1]:3d}  {r[0][:90]}")
     if len(sys.argv) > 6:
