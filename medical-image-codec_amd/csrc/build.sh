@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libmic_hip.so
 OBJ=build
-SRCS="mic_api.hip mic_host_io.hip mic_api_ext.hip mic_pica.hip mic_encode.hip mic_decode.hip mic_decode_ls.hip mic_decode_px.hip mic_decode_rows.hip mic_tables.hip mic_wavelet.hip mic_temporal.hip"
+SRCS="mic_api.hip mic_host_io.hip mic_api_ext.hip mic_pica.hip mic_encode.hip mic_decode.hip mic_decode_ls.hip mic_decode_px.hip mic_decode_rows.hip mic_decode_fused.hip mic_tables.hip mic_wavelet.hip mic_temporal.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${EXTRA_FLAGS:-}"
 mkdir -p $OBJ
 # a change of flags rebuilds everything

@@ -47,6 +47,7 @@ __device__ __forceinline__ uint32_t fn_compose(uint32_t g, uint32_t f) {
 __global__ void __launch_bounds__(PX_THREADS, 8) k_dec_pixels_wg(MicUnit *units) {
     MicUnit &u = units[blockIdx.x];
     if (u.status != MICD_OK || u.mode != 0) return;
+    if (u.walk_ok == 4) return;                                         // k_dec_rows_tok (mic_decode_fused.hip) has made this unit's pixels
     __shared__ uint32_t s_fn[PX_WAVES + 1];
     __shared__ uint32_t s_misc[8];
     __shared__ uint32_t s_segx[PX_THREADS], s_segy[PX_THREADS + 1];
@@ -978,6 +979,12 @@ __global__ void __launch_bounds__(64) k_dec_predict_grad(MicUnit *units, int w_l
 }
 
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad, uint32_t pred_mask) {
+#ifndef MIC_NO_FUSED       // (A / B builds: the two-kernel path for every unit)
+    if (pred_mask & 0x7Fu) {
+        if (t) t->mark("k_dec_rows_tok");
+        mic_launch_decode_fused(d_units, n, stream, pred_mask & 0x7Fu);
+    }
+#endif
     if (t) t->mark("k_dec_pixels_wg");
     hipLaunchKernelGGL(k_dec_pixels_wg, dim3(n), dim3(PX_THREADS), 0, stream, d_units);
     // row-buffer classes so that ordinary widths keep many waves per CU: a row buffer is 2 bytes per column and unit, four units per

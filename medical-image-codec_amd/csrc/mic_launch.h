@@ -79,6 +79,8 @@ void mic_launch_pack(const MicUnit *d_units, int n, uint64_t *d_off, uint8_t *d_
 #define MIC_PRED_WIDE   0x400u          // k_dec_predict<1, 64>: wider
 void mic_launch_decode_pixels(MicUnit *d_units, int n, hipStream_t stream, MicTimer *t, bool any_grad = false, uint32_t pred_mask = ~0u);
 void mic_launch_decode_rows(MicUnit *d_units, int n, hipStream_t stream, uint32_t kmask);
+// tokens -> pixels in one kernel for the same widths (mic_decode_fused.hip); units it takes are marked walk_ok = 4 and skipped by the kernels behind it
+void mic_launch_decode_fused(MicUnit *d_units, int n, hipStream_t stream, uint32_t kmask);
 // Frames of MIC_ROWS_LO < columns <= MIC_ROWS_HI take the row-by-row predictor: pixels per lane and row (0: another kernel's frame)
 #define MIC_ROWS_LO 1008
 #define MIC_ROWS_HI 2688
