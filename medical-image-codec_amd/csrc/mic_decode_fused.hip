@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
     const uint32_t ntok = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.ntok), nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)u.nseg);
     const uint32_t nsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(u.nsym, min(u.sym_cap, 2u * npx + 2u)));
-    if (ntok < 2 || nseg < 1 || nsym < 1 || nseg > 16u * (uint32_t)H + 64u) return;
+    if (ntok < 8 || nseg < 1 || nsym < 1 || nseg > 16u * (uint32_t)H + 64u) return;
     const uintptr_t px_u = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)u.px_out >> 32)) << 32) |
                            (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)u.px_out);
     const uintptr_t tok_u = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)u.tok >> 32)) << 32) |
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
     // The loads of a row are ISSUED one row ahead -- behind the row before's symbols, in front of its predictor and its stores -- and
     // LANDED (registers -> LDS) when that row has left: the wait for them is then a wait for loads that have had a whole row's time,
     // and not one behind the stores just issued (the memory counter is in order).
-    rf_v4 nx[NVJ]; uint32_t nx_kind = 0, nx_bval = 0, nx_ep = 0xFFFFFFFFu;   // kinds: 2 bits per round; the boundary element this lane carries
+    rf_v4 nx[NVJ]; uint32_t nx_kind = 0, nx_bval = 0, nx_ep = 0xFFFFFFFFu;   // 5 bits per round: kind (1 literal vector, 2 run), the run value's place in its vector; the boundary element this lane carries
 #pragma unroll
     for (int r = 0; r < NVJ; r++) nx[r] = rf_v4{0u, 0u, 0u, 0u};
     auto issue = [&](uint32_t spos, uint32_t to) -> int {
@@ -181,13 +181,17 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
                 else if (x + (hi_ - ys) > ntok) return 0;                 // (a literal run past the end: the other path reports it)
                 const uint32_t plo = s - spos, phi = hi_ - spos, rel = x + spos - ys;   // literal: token of row position q = rel + q
                 const uint32_t r_lo = plo >> 9, r_hi = (phi - 1u) >> 9;
+                // (a run's value comes in the same kind of load as a literal vector -- the eight tokens that hold it, the last eight
+                // of the unit at most: two kinds of load into one register made the compiler wait for the first before it issued the
+                // second, six memory round trips a row)
+                const uint32_t xb = min(x, ntok - 8u), xsh = x - xb;
 #pragma unroll
                 for (int r = 0; r < NVJ; r++) {
                     if ((uint32_t)r >= r_lo && (uint32_t)r <= r_hi) {        // (wave-uniform: a scalar branch)
                         const uint32_t vlo = 8u * (lane + 64u * (uint32_t)r);
                         const bool inside = vlo >= plo && vlo + 8u <= phi;
-                        kind[r] = inside ? (run ? 2u : 1u) : kind[r];
-                        off[r] = inside ? (run ? x : rel + vlo) : off[r];
+                        kind[r] = inside ? (run ? 2u + (xsh << 2) : 1u) : kind[r];
+                        off[r] = inside ? (run ? xb : rel + vlo) : off[r];
                     }
                 }
                 if (P == bslot) ep = ((phi & 7u) != 0u) ? (phi & ~7u) + bk : 0xFFFFFFFFu;
@@ -203,9 +207,8 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
         nx_kind = 0;
 #pragma unroll
         for (int r = 0; r < NVJ; r++) {
-            if (kind[r] == 1u) nx[r] = *(const __attribute__((address_space(1))) RfQ *)(tok + off[r]);
-            else if (kind[r] == 2u) nx[r].x = tok[off[r]];
-            nx_kind |= kind[r] << (2 * r);
+            if (kind[r] != 0u) nx[r] = *(const __attribute__((address_space(1))) RfQ *)(tok + off[r]);
+            nx_kind |= kind[r] << (5 * r);
         }
         nx_ep = bhave ? ep : 0xFFFFFFFFu;
         if (bhave) nx_bval = tok[bsrc];
@@ -215,9 +218,13 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
     auto land = [&]() {
 #pragma unroll
         for (int r = 0; r < NVJ; r++) {
-            const uint32_t d = lane + 64u * (uint32_t)r, kd = (nx_kind >> (2 * r)) & 3u;
+            const uint32_t d = lane + 64u * (uint32_t)r, kf = (nx_kind >> (5 * r)) & 31u, kd = kf & 3u, sh = kf >> 2;
             rf_v4 v = nx[r];
-            if (kd == 2u) { const uint32_t w = v.x | (v.x << 16); v = rf_v4{w, w, w, w}; }
+            if (kd == 2u) {                                              // a run: token `sh` of the eight, in every position
+                const uint32_t dw = (sh & 4u) ? ((sh & 2u) ? v.w : v.z) : ((sh & 2u) ? v.y : v.x);
+                const uint32_t h = (sh & 1u) ? (dw >> 16) : (dw & 0xFFFFu), w = h | (h << 16);
+                v = rf_v4{w, w, w, w};
+            }
             if (kd != 0u) *(uint4 *)(sb + 4u * d) = make_uint4(v.x, v.y, v.z, v.w);
         }
         if (nx_ep != 0xFFFFFFFFu) sb16[nx_ep] = (uint16_t)nx_bval;
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
     };
 
 #ifdef RF_STATS     // diagnostic build: rows by path and shader-clock ticks by phase, in u.dbg (tools/time_fused.py)
-    uint32_t st_rows[4] = { 0, 0, 0, 0 }; uint64_t st_t[4] = { 0, 0, 0, 0 }, st_prev = __builtin_amdgcn_s_memtime();
+    uint32_t st_rows[4] = { 0, 0, 0, 0 }; uint64_t st_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, st_prev = __builtin_amdgcn_s_memtime();
 #define RF_T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_t[i] += t_ - st_prev; st_prev = t_; } while (0)
 #define RF_ROW(i) (st_rows[i]++)
 #else
@@ -256,6 +263,15 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
     for (int y = 0; y < H; y++) {
         if (ar > 0) land();
         else { RF_ROW(1); if (!assemble(spos, 0u, (uint32_t)W)) return; } // (more than eight pieces: piece by piece)
+        // What lies behind the row's end in the row buffer (the next row's first symbols, or the results staged for the last store) is
+        // computed along by the last lanes: there it must be the symbol that changes nothing, or a stale result would look like a
+        // wrap-around to the predictor.  Fewer than 256 positions -- written here, after the row (LDS operations of a wave are in
+        // order), instead of a select per dword of every lane's chunk.
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t i = (uint32_t)W + lane + 64u * (uint32_t)t;
+            if (i < 64u * K) sb16[i] = (uint16_t)thr;
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         RF_T(0);
         // A delimiter is the largest value a symbol takes (anything above it can only be the payload behind one, or a damaged stream's):
@@ -265,16 +281,14 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
         rf_pk2 mx = { 0, 0 };
 #pragma unroll
         for (int q = 0; q < KD; q++) {
-            // (the pixel behind the row's last one shares a dword with it: as a symbol it must be the one that changes nothing, not
-            // whatever the buffer held -- a result of the row before would look like a wrap-around to the predictor)
-            const uint32_t ld = sb[lane * KD + q];
-            const uint32_t w = (2 * q + 2 <= nv) ? ld : (2 * q + 1 == nv) ? ((ld & 0xFFFFu) | (thr << 16)) : thr2;
-            e[q] = w;
-            mx = __builtin_elementwise_max(mx, __builtin_bit_cast(rf_pk2, w));
+            e[q] = sb[lane * KD + q];
         }
+#pragma unroll
+        for (int q = 0; q < KD; q++) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(rf_pk2, e[q]));
         const uint32_t hasd = ((uint32_t)mx.x >= delim || (uint32_t)mx.y >= delim) ? 1u : 0u;
         uint32_t used = (uint32_t)W;
         const bool esc_row = __any(hasd != 0u);
+        RF_T(4);
         if (esc_row) {
             RF_ROW(2);
             // ---- escapes in this row: markers, pixel numbering, raw bits (k_dec_pixels_wg's scan, one wave) ----
@@ -355,6 +369,7 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
         }
         RowSymsLds es{ pb + lane * KD };
         __builtin_amdgcn_s_waitcnt(0xC07F);                             // (the buffers are read: the row's results may go in)
+        RF_T(5);
         // the next row's loads go out now: its first symbol is known, and nothing of the predictor or of put() touches their registers
         if (y + 1 < H) {
             if (spos + used + (uint32_t)W > nsym) return;
@@ -382,7 +397,7 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
         spos += used;
     }
 #ifdef RF_STATS
-    if (lane == 0) { for (int i = 0; i < 4; i++) { u.dbg[i] = st_rows[i]; u.dbg[4 + i] = (uint32_t)(st_t[i] >> 4); } }
+    if (lane == 0) { for (int i = 0; i < 4; i++) { u.dbg[i] = st_rows[i]; u.dbg[4 + i] = (uint32_t)(st_t[i] >> 4); } u.dbg[1] = (uint32_t)(st_t[4] >> 4); u.dbg[2] = (uint32_t)(st_t[5] >> 4); }
 #endif
     if (lane == 0) { u.dec_thr = thr; u.walk_ok = 4; }                   // pixels done: the two-kernel path skips this unit
 }

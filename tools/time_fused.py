@@ -31,8 +31,8 @@ for i in range(len(units)):
     L.mic_hip_debug_unit(sess._h, i, out)
     tot += np.array([out[16 + k] for k in range(8)], dtype=np.int64)
 n = len(units)
-print("per unit: rows %.1f, slow-assembly rows %.1f, escape rows %.1f, wrapped rows %.1f" % tuple(tot[:4] / n))
-print("per unit, 1e3 ticks (x16): assemble %.1f, symbols/escapes %.1f, predictor %.1f, put %.1f" % tuple(tot[4:] / n / 1e3))
+print("per unit: rows %.1f, [ticks: chunk reads + delimiter test %.1f, escapes + e to LDS %.1f], wrapped rows %.1f" % (tot[0] / n, tot[1] / n / 1e3, tot[2] / n / 1e3, tot[3] / n))
+print("per unit, 1e3 ticks (x16): assemble %.1f, issue %.1f, predictor %.1f, put %.1f" % tuple(tot[4:] / n / 1e3))
 for i in (0, 7, 1000):
     L.mic_hip_debug_unit(sess._h, i, out)
     print("unit", i, [out[16 + k] for k in range(8)])
