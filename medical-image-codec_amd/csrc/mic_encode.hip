@@ -966,7 +966,13 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
             if (tid > 0 && e_prev != assumed[k]) { assumed[k] = e_prev; any = true; }
             st2[k] = e_prev;
         }
-        if (any) {
+        // (a thread without tokens -- the tail of the group when the blocks do not divide by it -- takes no part: handing the end
+        // states on through those threads was a round each, 8 to 22 rounds on an XR strip instead of one -- cheap ones, three
+        // barriers and no walk, nothing the kernel's time shows; the trailer takes the states from the last thread that owns tokens,
+        // below.  What the fix-up costs is its ONE round: merge lengths halve every ~128 tokens, the slowest of 512 threads walks
+        // ~1000 tokens again, and its wave -- and, at the barrier, the group -- waits for it: stamps walk 265 k, fix-up 300 k,
+        // pack 640 k ticks.  A longer warm-up moves that time into the walk, token for token: tools/stamp_enc.py, TE_WARM_TOK.)
+        if (any && b_hi > b_lo) {
             bool merged = false;
 #ifdef MIC_STAMP
             atomicAdd(&u.dbg[13], 1u);                                    // threads that re-walk, all rounds
@@ -985,7 +991,7 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
                 mybits += bits - old_bits;
                 rec_store(g, st2, bits);
             }
-            if (!merged) {                                   // ran to the end of the range (or owns no tokens): hand the states on
+            if (!merged) {                                   // ran to the end of the range: hand the states on
 #pragma unroll
                 for (int k = 0; k < N; k++) if (st2[k] != e_out[k]) { e_out[k] = st2[k]; changed = 1; }
             }
