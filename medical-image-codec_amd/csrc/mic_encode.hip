@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 #define TE_BLK2 64                // tokens per block of the one- and two-state walks
 #endif
 #ifndef TE_ABL
-#define TE_ABL 0         // timing-only ablations: 1 = every block read comes from the unit's first 4 KiB, 2 = the pack pass stores nothing
+#define TE_ABL 0         // timing-only ablations: 1 = every block read comes from the unit's first 4 KiB, 2 = the pack pass stores nothing (and is optimised away), 4 = it does its work and stores nothing
 #endif
 #define TE_ABL_BASE(b) ((TE_ABL & 1) ? ((b) & 2047u) : (b))
 #define TE_TT_SYMS 4096           // alphabets up to this size keep their coding records in LDS (32 KiB)
@@ -1072,8 +1072,10 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
     uint64_t lead_val = 0; bool have_lead = false;
     uint64_t pend = 0; bool have_pend = false;                            // the even unit of a pair, waiting for its odd partner
     typedef unsigned long long te_u2 __attribute__((ext_vector_type(2)));
+    uint64_t abl_chk = 0;
     auto emit = [&](uint64_t v) {                                          // unit q is complete (or the thread's last, partial one)
         if (TE_ABL & 2) { q++; return; }
+        if (TE_ABL & 4) { abl_chk ^= v; q++; return; }                          // (timing only: the pass without its stores)
         if (q == first_q && !own_first) { lead_val = v; have_lead = true; }
         else if (q & 1u) {
             if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(mic_gp<te_u2>)(words64 + (q - 1)) = pr; have_pend = false; }
@@ -1132,6 +1134,7 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
 #endif
     }
     if (mybits > 0 && filled > 0) emit(acc);                             // the thread's last, partial unit
+    if ((TE_ABL & 4) && abl_chk == 0x1234567ull) words64[first_q] = abl_chk;
     if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
 #ifdef TE_NO_HANDOFF    // diagnostic: the barrier round 3 had here before MIC_GROUP_HANDOFF
     __threadfence_block(); __syncthreads();
