@@ -70,151 +70,155 @@ __device__ __forceinline__ void wv_pair(Get cf, int n, int i, int32_t &ev, int32
     od = 0;
     if (2 * i + 1 < n) { const int32_t rr = (2 * i + 2 < n) ? wv_even(cf, n, i + 1) : ev; od = cf(n_low + i) + ((ev + rr) >> 1); }
 }
-// ---- one level of the transform in ONE pass -----------------------------------------------------------------------------------
-// Rows pass and columns pass fused over a tile kept in LDS: a level reads its input once and writes its four subbands once (level 0:
-// 2 + 4 bytes per sample instead of 2 + 4 + 4 + 4; the two-pass kernels of rounds 1-2 moved 19 N bytes per transform, these move 9 N:
-// 14.3 -> 11.4 ms for 256 CR frames both ways -- the tile's index arithmetic, not memory, is what is left).
-// A tile is WT_W x WT_H output PAIRS (2 WT_W x 2 WT_H input samples) + the three samples of context the lifting reaches to on
-// either axis; the per-sample rules are the ones above (wv_s, wv_d, wv_pair) over accessors that map global indices into the tile,
-// so the boundary handling is theirs.  The detail subbands go to their Mallat places in `a` (row stride `stride`); the smooth
-// subband -- the next level's input -- goes to a compact scratch plane (`ll`, row stride = its width), except the last level's,
-// which goes to the top-left corner of `a`: nothing is read and written in the same buffer by one launch.
-#define WT_W 64
-#define WT_H 16
+// ---- one level of the transform in ONE pass, no LDS ------------------------------------------------------------------------------
+// A lane owns one column PAIR (samples 2 gi, 2 gi + 1 of every row) and walks down a strip of rows.  The rows pass of a row needs
+// the neighbour lanes' samples only -- x[2 gi + 2] from the lane to the right, d[gi - 1] from the lane to the left: two DPP wave
+// shifts -- and the columns pass is a window of three rows of the rows pass's output that slides down the lane's registers.  A wave
+// covers 64 pairs and writes 62 (one pair of context on either side), a strip is WS_ROWS output rows (+ one pair of rows of
+// context at its top); every access is a run of 256 bytes (128 for 16-bit pixels) per wave, the addresses advance by a stride a row.
+// (Rounds 2-3: rows and columns over a 64 x 16 tile in LDS -- one pass over memory as well, 9 N bytes a transform, but ~100
+// instructions of tile index arithmetic per sample: 4.9 + 6.4 ms for 256 CR frames both ways where the memory traffic is ~4.)
+// The detail subbands go to their Mallat places in `a` (row stride `stride`); the smooth subband -- the next level's input -- goes to
+// a compact scratch plane (`ll`, row stride = its width), except the last level's, which goes to the top-left corner of `a`:
+// nothing is read and written in the same buffer by one launch.
+#define WS_ROWS 64
+#define WS_LANES 62                 // pairs a wave writes
+template <int CTRL> __device__ __forceinline__ int32_t wv_shift(int32_t v) {    // 0x130: from the lane to the right, 0x138: from the lane to the left
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+typedef uint32_t wv_u32u __attribute__((aligned(2)));
+typedef unsigned long long wv_u64u __attribute__((aligned(4)));
+
 template <bool FROM_U16>
 __global__ void __launch_bounds__(256) k_wv_fwd2d(const void *__restrict__ src_, int sstride, size_t sfs, int32_t *__restrict__ a, int stride, size_t fs,
                                                   int32_t *__restrict__ ll, int llstride, size_t llfs, int r, int c, int nf) {
-    constexpr int IW = 2 * WT_W + 3, IH = 2 * WT_H + 3;
-    __shared__ int32_t s_in[IH][IW + 1];
-    __shared__ int32_t s_lo[IH][WT_W], s_hi[IH][WT_W];
-    const int tid = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int nlc = (c + 1) / 2, nlr = (r + 1) / 2;
-    const int I0 = (int)blockIdx.x * WT_W, Y0 = (int)blockIdx.y * WT_H;
-    const int j0 = 2 * I0 - 2, y0 = 2 * Y0 - 2;
-    // a tile whose every sample has both neighbours on an axis takes the lifting without the boundary rules there
-    const bool in_x = I0 > 0 && 2 * (I0 + WT_W) + 2 < c, in_y = Y0 > 0 && 2 * (Y0 + WT_H) + 2 < r;
+    const int gi = ((int)blockIdx.x * 4 + wave) * WS_LANES - 1 + lane;          // this lane's pair (lanes 0 and 63: context only)
+    const int gp0 = (int)blockIdx.y * WS_ROWS, gp1 = min(gp0 + WS_ROWS, nlr);
+    if (((int)blockIdx.x * 4 + wave) * WS_LANES >= nlc) return;
+    const bool has0 = gi >= 0 && 2 * gi < c, has1 = gi >= 0 && 2 * gi + 1 < c, hasr = 2 * gi + 2 < c, left = gi > 0;
+    const bool out_lo = lane >= 1 && lane <= WS_LANES && has0, out_hi = lane >= 1 && lane <= WS_LANES && has1;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z) {
-        for (int idx = tid; idx < IH * IW; idx += 256) {
-            const int ly = idx / IW, lx = idx - ly * IW, gy = y0 + ly, gx = j0 + lx;
-            int32_t v = 0;
-            if (gy >= 0 && gy < r && gx >= 0 && gx < c) {
-                const size_t o = (size_t)f * sfs + (size_t)gy * sstride + gx;
-                v = FROM_U16 ? (int32_t)((const uint16_t *)src_)[o] : ((const int32_t *)src_)[o];
+        // input row y: this lane's two samples ...
+        auto fetch = [&](int y, int32_t &x0, int32_t &x1) {
+            x0 = 0; x1 = 0;
+            const size_t o = (size_t)f * sfs + (size_t)y * sstride + (size_t)(2 * gi);
+            if (FROM_U16) {
+                const uint16_t *p = (const uint16_t *)src_ + o;
+                if (has1) { const uint32_t w = *(const wv_u32u *)p; x0 = (int32_t)(w & 0xFFFFu); x1 = (int32_t)(w >> 16); }
+                else if (has0) x0 = (int32_t)p[0];
+            } else {
+                const int32_t *p = (const int32_t *)src_ + o;
+                if (has1) { const unsigned long long w = *(const wv_u64u *)p; x0 = (int32_t)(uint32_t)w; x1 = (int32_t)(uint32_t)(w >> 32); }
+                else if (has0) x0 = p[0];
             }
-            s_in[ly][lx] = v;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < IH * WT_W; idx += 256) {                      // rows of the tile (waveletu16.go:170-182)
-            const int ly = idx / WT_W, li = idx - ly * WT_W, gy = y0 + ly, gi = I0 + li;
-            if (gy < 0 || gy >= r || gi >= nlc) continue;
-            if (in_x) {
-                const int32_t *x = &s_in[ly][2 * li];                            // x[2] = sample 2 gi
-                const int32_t dl = x[1] - ((x[0] + x[2]) >> 1), dr = x[3] - ((x[2] + x[4]) >> 1);
-                s_lo[ly][li] = x[2] + ((dl + dr + 2) >> 2); s_hi[ly][li] = dr;
-                continue;
+        };
+        // ... and its rows pass (waveletu16.go:26-74, :170-182): smooth and detail of the pair
+        auto lift = [&](int32_t x0, int32_t x1, int32_t &lo, int32_t &hi) {
+            const int32_t xn = wv_shift<0x130>(x0), xr = hasr ? xn : x0;       // symmetric extension on the right
+            const int32_t d = x1 - ((x0 + xr) >> 1);
+            const int32_t dp = wv_shift<0x138>(d);
+            const int32_t dr = has1 ? d : (left ? dp : 0), dl = left ? dp : dr;
+            lo = x0 + ((dl + dr + 2) >> 2); hi = d;
+        };
+        auto row = [&](int y, int32_t &lo, int32_t &hi) { int32_t x0, x1; fetch(y, x0, x1); lift(x0, x1, lo, hi); };
+        // the columns pass (:183-208) down the strip: rows 2 gp, 2 gp + 1 in (l0, h0), (l1, h1); row 2 gp + 2 in (ln, hn)
+        int32_t l0, h0, l1 = 0, h1 = 0, ln = 0, hn = 0, dlo = 0, dhi = 0;       // dlo, dhi: the details of pair-row gp - 1
+        if (gp0 > 0) {
+            int32_t pl0, ph0, pl1, ph1;
+            row(2 * gp0 - 2, pl0, ph0); row(2 * gp0 - 1, pl1, ph1); row(2 * gp0, l0, h0);
+            dlo = pl1 - ((pl0 + l0) >> 1); dhi = ph1 - ((ph0 + h0) >> 1);
+        } else row(0, l0, h0);
+        if (2 * gp0 + 1 < r) row(2 * gp0 + 1, l1, h1);
+        for (int gp = gp0; gp < gp1; gp++) {
+            const bool odd = 2 * gp + 1 < r, more = 2 * gp + 2 < r, more1 = 2 * gp + 3 < r;
+            int32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;                              // (both rows of the next pair are fetched before either is used)
+            if (more) fetch(2 * gp + 2, a0, a1);
+            if (more1) fetch(2 * gp + 3, b0, b1);
+            if (more) lift(a0, a1, ln, hn);
+            const int32_t rl = more ? ln : l0, rh = more ? hn : h0;
+            const int32_t d_l = l1 - ((l0 + rl) >> 1), d_h = h1 - ((h0 + rh) >> 1);
+            const int32_t drl = odd ? d_l : (gp > 0 ? dlo : 0), drh = odd ? d_h : (gp > 0 ? dhi : 0);
+            const int32_t dll = gp > 0 ? dlo : drl, dlh = gp > 0 ? dhi : drh;
+            const int32_t s_l = l0 + ((dll + drl + 2) >> 2), s_h = h0 + ((dlh + drh + 2) >> 2);
+            if (out_lo) ll[(size_t)f * llfs + (size_t)gp * llstride + gi] = s_l;
+            if (out_hi) a[(size_t)f * fs + (size_t)gp * stride + nlc + gi] = s_h;
+            if (odd) {
+                if (out_lo) a[(size_t)f * fs + (size_t)(nlr + gp) * stride + gi] = d_l;
+                if (out_hi) a[(size_t)f * fs + (size_t)(nlr + gp) * stride + nlc + gi] = d_h;
             }
-            auto x = [&](int j) { return s_in[ly][j - j0]; };
-            s_lo[ly][li] = wv_s(x, c, gi);
-            if (2 * gi + 1 < c) s_hi[ly][li] = wv_d(x, c, gi);
+            dlo = d_l; dhi = d_h; l0 = ln; h0 = hn;
+            if (more1) lift(b0, b1, l1, h1);
         }
-        __syncthreads();
-        for (int idx = tid; idx < 2 * WT_W * WT_H; idx += 256) {                // columns (:183-208): both halves of the rows' output
-            const int lp = idx / (2 * WT_W), col = idx - lp * (2 * WT_W), hi = col >= WT_W, li = hi ? col - WT_W : col;
-            const int gp = Y0 + lp, gi = I0 + li;
-            if (gp >= nlr || gi >= nlc || (hi && 2 * gi + 1 >= c)) continue;
-            if (in_y) {
-                const int32_t (*p)[WT_W] = hi ? s_hi : s_lo;
-                const int b = 2 * lp;                                            // row b + 2 = sample 2 gp
-                const int32_t x0 = p[b][li], x1 = p[b + 1][li], x2 = p[b + 2][li], x3 = p[b + 3][li], x4 = p[b + 4][li];
-                const int32_t dl = x1 - ((x0 + x2) >> 1), dr = x3 - ((x2 + x4) >> 1), sv = x2 + ((dl + dr + 2) >> 2);
-                if (hi) a[(size_t)f * fs + (size_t)gp * stride + nlc + gi] = sv;
-                else ll[(size_t)f * llfs + (size_t)gp * llstride + gi] = sv;
-                a[(size_t)f * fs + (size_t)(nlr + gp) * stride + (hi ? nlc : 0) + gi] = dr;
-                continue;
-            }
-            auto x = [&](int j) { return hi ? s_hi[j - y0][li] : s_lo[j - y0][li]; };
-            const int32_t sv = wv_s(x, r, gp);
-            if (hi) a[(size_t)f * fs + (size_t)gp * stride + nlc + gi] = sv;
-            else ll[(size_t)f * llfs + (size_t)gp * llstride + gi] = sv;
-            if (2 * gp + 1 < r) a[(size_t)f * fs + (size_t)(nlr + gp) * stride + (hi ? nlc : 0) + gi] = wv_d(x, r, gp);
-        }
-        __syncthreads();
     }
 }
 // The inverse of one level (columns, then rows: waveletu16.go:213-257): the smooth subband from `ll` (the level below wrote it; the
 // coarsest level's lies in `a`), the detail subbands from `a`, the restored region to `dst` (a compact plane, or the 16-bit pixels).
+// A lane owns smooth column gi and detail column gi of the Mallat layout -- after the rows pass, samples 2 gi and 2 gi + 1.
 template <bool TO_U16>
 __global__ void __launch_bounds__(256) k_wv_inv2d(const int32_t *__restrict__ a, int stride, size_t fs, const int32_t *__restrict__ ll, int llstride, size_t llfs,
                                                   void *__restrict__ dst_, int dstride, size_t dfs, int r, int c, int nf) {
-    // Mallat columns a tile's rows pass needs: smooth I0 .. I0 + WT_W, detail I0 - 1 .. I0 + WT_W; rows likewise
-    constexpr int CW = 2 * WT_W + 3, CH = 2 * WT_H + 3;
-    __shared__ int32_t s_q[CH][CW + 1];                                         // [smooth rows | detail rows] x [smooth cols | detail cols]
-    __shared__ int32_t s_c[2 * WT_H][CW + 1];                                   // after the columns pass: 2 WT_H restored rows of those columns
-    const int tid = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int nlc = (c + 1) / 2, nlr = (r + 1) / 2;
-    const int I0 = (int)blockIdx.x * WT_W, Y0 = (int)blockIdx.y * WT_H;
-    // local column lx <-> Mallat column: lx < WT_W + 1: smooth I0 + lx; else detail I0 - 1 + (lx - (WT_W + 1))
-    auto mcol = [&](int lx, bool &hi) { hi = lx > WT_W; return hi ? I0 - 1 + (lx - (WT_W + 1)) : I0 + lx; };
-    const bool in_x = I0 > 0 && 2 * (I0 + WT_W) + 1 < c, in_y = Y0 > 0 && 2 * (Y0 + WT_H) + 1 < r;   // (no boundary rule applies on that axis)
+    const int gi = ((int)blockIdx.x * 4 + wave) * WS_LANES - 1 + lane;
+    const int gp0 = (int)blockIdx.y * WS_ROWS, gp1 = min(gp0 + WS_ROWS, nlr);
+    if (((int)blockIdx.x * 4 + wave) * WS_LANES >= nlc) return;
+    const bool has0 = gi >= 0 && 2 * gi < c, has1 = gi >= 0 && 2 * gi + 1 < c, hasr = 2 * gi + 2 < c, left = gi > 0;
+    const bool out0 = lane >= 1 && lane <= WS_LANES && has0;
     for (int f = (int)blockIdx.z; f < nf; f += (int)gridDim.z) {
-        for (int idx = tid; idx < CH * CW; idx += 256) {
-            const int ly = idx / CW, lx = idx - ly * CW;
-            bool hx, hy = ly > WT_H;
-            const int gx = mcol(lx, hx), gy = hy ? Y0 - 1 + (ly - (WT_H + 1)) : Y0 + ly;
-            int32_t v = 0;
-            const bool okx = gx >= 0 && (hx ? gx < c - nlc : gx < nlc), oky = gy >= 0 && (hy ? gy < r - nlr : gy < nlr);
-            if (okx && oky) {
-                if (!hx && !hy) v = ll[(size_t)f * llfs + (size_t)gy * llstride + gx];
-                else v = a[(size_t)f * fs + (size_t)((hy ? nlr : 0) + gy) * stride + (hx ? nlc : 0) + gx];
-            }
-            s_q[ly][lx] = v;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < WT_H * CW; idx += 256) {                      // columns: pair lp of local column lx
-            const int lp = idx / CW, lx = idx - lp * CW, gp = Y0 + lp;
-            bool hx;
-            const int gx = mcol(lx, hx);
-            if (gp >= nlr || gx < 0 || (hx ? gx >= c - nlc : gx >= nlc)) continue;
-            if (in_y) {                                                         // smooth rows lp, lp + 1; detail rows gp - 1 .. gp + 1
-                const int32_t c0 = s_q[lp][lx], c1 = s_q[lp + 1][lx], dm = s_q[WT_H + 1 + lp][lx], d0 = s_q[WT_H + 2 + lp][lx], dp = s_q[WT_H + 3 + lp][lx];
-                const int32_t e0 = c0 - ((dm + d0 + 2) >> 2), e1 = c1 - ((d0 + dp + 2) >> 2);
-                s_c[2 * lp][lx] = e0; s_c[2 * lp + 1][lx] = d0 + ((e0 + e1) >> 1);
-                continue;
-            }
-            auto cf = [&](int j) { return j < nlr ? s_q[j - Y0][lx] : s_q[WT_H + 1 + (j - nlr) - (Y0 - 1)][lx]; };
-            int32_t ev, od; wv_pair(cf, r, gp, ev, od);
-            s_c[2 * lp][lx] = ev;
-            if (2 * gp + 1 < r) s_c[2 * lp + 1][lx] = od;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 2 * WT_H * WT_W; idx += 256) {                // rows: pair li of local row ly
-            const int ly = idx / WT_W, li = idx - ly * WT_W, gy = 2 * Y0 + ly, gi = I0 + li;
-            if (gy >= r || gi >= nlc) continue;
-            int32_t ev, od;
-            if (in_x) {
-                const int32_t *q = &s_c[ly][0];
-                const int32_t dm = q[WT_W + 1 + li], d0 = q[WT_W + 2 + li], dp = q[WT_W + 3 + li];
-                ev = q[li] - ((dm + d0 + 2) >> 2);
-                od = d0 + ((ev + (q[li + 1] - ((d0 + dp + 2) >> 2))) >> 1);
-            } else {
-                auto cf = [&](int j) { return j < nlc ? s_c[ly][j - I0] : s_c[ly][WT_W + 1 + (j - nlc) - (I0 - 1)]; };
-                wv_pair(cf, c, gi, ev, od);
-            }
-            const size_t o = (size_t)f * dfs + (size_t)gy * dstride + 2 * gi;
+        const int32_t *af = a + (size_t)f * fs, *lf = ll + (size_t)f * llfs;
+        // Mallat row j of this lane's two columns: smooth rows j < nlr, detail rows nlr + j
+        auto smooth = [&](int j, int32_t &vs, int32_t &vd) {
+            vs = has0 ? lf[(size_t)j * llstride + gi] : 0;
+            vd = has1 ? af[(size_t)j * stride + nlc + gi] : 0;
+        };
+        auto detail = [&](int j, int32_t &vs, int32_t &vd) {
+            vs = has0 ? af[(size_t)(nlr + j) * stride + gi] : 0;
+            vd = has1 ? af[(size_t)(nlr + j) * stride + nlc + gi] : 0;
+        };
+        // even sample j of a column from its smooth value and the details on either side (wv_even's rules)
+        auto even = [&](int j, int32_t cs, int32_t dm, int32_t d0) -> int32_t {
+            const int32_t dr = (2 * j + 1 < r) ? d0 : (j > 0 ? dm : 0), dl = j > 0 ? dm : dr;
+            return cs - ((dl + dr + 2) >> 2);
+        };
+        // one restored row of the columns pass through the rows pass, to `dst`
+        auto put = [&](int y, int32_t vs, int32_t vd) {
+            const int32_t dp = wv_shift<0x138>(vd);
+            const int32_t dr = has1 ? vd : (left ? dp : 0), dl = left ? dp : dr;
+            const int32_t ev = vs - ((dl + dr + 2) >> 2);
+            const int32_t en = wv_shift<0x130>(ev);
+            const int32_t od = vd + ((ev + (hasr ? en : ev)) >> 1);
+            if (!out0) return;
+            const size_t o = (size_t)f * dfs + (size_t)y * dstride + (size_t)(2 * gi);
             if (TO_U16) {
-                typedef uint32_t wv_u32u __attribute__((aligned(2)));            // (a pixel pair in one store; rows of odd width start on odd pixels)
                 uint16_t *d = (uint16_t *)dst_ + o;
-                if (2 * gi + 1 < c) *(wv_u32u *)d = ((uint32_t)ev & 0xFFFFu) | ((uint32_t)od << 16); else d[0] = (uint16_t)ev;
+                if (has1) *(wv_u32u *)d = ((uint32_t)ev & 0xFFFFu) | ((uint32_t)od << 16); else d[0] = (uint16_t)ev;
             } else {
-                typedef unsigned long long wv_u64u __attribute__((aligned(4)));
                 int32_t *d = (int32_t *)dst_ + o;
-                if (2 * gi + 1 < c) *(wv_u64u *)d = (uint32_t)ev | ((unsigned long long)(uint32_t)od << 32); else d[0] = ev;
+                if (has1) *(wv_u64u *)d = (uint32_t)ev | ((unsigned long long)(uint32_t)od << 32); else d[0] = ev;
             }
+        };
+        // the columns pass down the strip: (es, ed) = even sample gp of the two columns, (ds, dd) = their details gp
+        int32_t ss, sd, ds = 0, dd = 0, pms = 0, pmd = 0;
+        if (gp0 > 0) detail(gp0 - 1, pms, pmd);
+        smooth(gp0, ss, sd);
+        if (2 * gp0 + 1 < r) detail(gp0, ds, dd);
+        int32_t es = even(gp0, ss, pms, ds), ed = even(gp0, sd, pmd, dd);
+        for (int gp = gp0; gp < gp1; gp++) {
+            const bool odd = 2 * gp + 1 < r, more = 2 * gp + 2 < r;
+            int32_t ns = 0, nd = 0, nds = 0, ndd = 0, es1 = es, ed1 = ed;
+            if (more) {
+                smooth(gp + 1, ns, nd);
+                if (2 * gp + 3 < r) detail(gp + 1, nds, ndd);
+                es1 = even(gp + 1, ns, ds, nds); ed1 = even(gp + 1, nd, dd, ndd);
+            }
+            put(2 * gp, es, ed);
+            if (odd) put(2 * gp + 1, ds + ((es + es1) >> 1), dd + ((ed + ed1) >> 1));
+            es = es1; ed = ed1; ds = nds; dd = ndd;
         }
-        __syncthreads();
     }
 }
-// (a frame the transform leaves untouched: zero levels)
 __global__ void __launch_bounds__(256) k_wv_load(const uint16_t *px, int32_t *a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = (int32_t)px[i];
 }
@@ -783,7 +787,7 @@ int wv_compress_frames(mic_hip_session *s, const uint16_t *d_src, int nf, int ro
     { int r = rows, c = cols;
       for (int l = 0; l < applied; l++) {                                  // a level per launch: level l's smooth plane in B, parity l
           const int rn = (r + 1) / 2, cn = (c + 1) / 2;
-          const dim3 g((unsigned)((cn + WT_W - 1) / WT_W), (unsigned)((rn + WT_H - 1) / WT_H), (unsigned)std::min(nf, 65535));
+          const dim3 g((unsigned)((cn + 4 * WS_LANES - 1) / (4 * WS_LANES)), (unsigned)((rn + WS_ROWS - 1) / WS_ROWS), (unsigned)std::min(nf, 65535));
           const bool last = l == applied - 1;
           int32_t *lld = last ? A : B + ((l & 1) ? ll_half : 0);
           const int lls = last ? cols : cn; const size_t llf = last ? n : ll_fs;
@@ -864,7 +868,7 @@ int wv_decompress_frames(mic_hip_session *s, const uint8_t *d_comp, uint16_t *d_
     if (levels == 0) hipLaunchKernelGGL(k_wv_store, dim3(grid_for(n * (size_t)nf)), dim3(256), 0, s->stream, (const int32_t *)A, d_dst, n * (size_t)nf);
     for (int l = levels - 1; l >= 0; l--) {                                                 // coarse -> fine, :519-527
         const int r = d.nr[l], cc = d.nc[l];
-        const dim3 g((unsigned)(((cc + 1) / 2 + WT_W - 1) / WT_W), (unsigned)(((r + 1) / 2 + WT_H - 1) / WT_H), (unsigned)std::min(nf, 65535));
+        const dim3 g((unsigned)(((cc + 1) / 2 + 4 * WS_LANES - 1) / (4 * WS_LANES)), (unsigned)(((r + 1) / 2 + WS_ROWS - 1) / WS_ROWS), (unsigned)std::min(nf, 65535));
         const bool coarsest = l == levels - 1;
         const int32_t *lls = coarsest ? A : B + (((l + 1) & 1) ? ll_half : 0);
         const int llst = coarsest ? cols : d.nc[l + 1]; const size_t llf = coarsest ? n : ll_fs;
