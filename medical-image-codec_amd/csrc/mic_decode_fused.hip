@@ -161,49 +161,63 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
             if (sg + 1 < nseg && seg_y(sg + 1) <= spos) sg++; else break;
         }
         if (sg + 10 >= wbase + 63) win_load(sg);                         // (room for the row's pieces)
-        // ONE walk over the row's pieces: checks, the vectors that lie inside a piece (only the rounds of 512 symbols the piece
-        // reaches into are looked at), the boundary element of the lanes that carry one
+        // The row's pieces, one per LANE (lane p: segment sg + p; at most eight are used, a ninth sends the row to the piece-by-piece
+        // form): the window's records are shuffled into place, every lane checks and describes its piece, and the vectors then find
+        // theirs by counting piece ends -- no walk from piece to piece (the first form: ~110 scalar-unit instructions a piece, 40 %
+        // of the kernel).  A piece is needed iff it begins in front of the row's end; the y of a record behind the last is nsym.
+        const uint32_t end = spos + to;
+        const uint32_t wl = min(sg - wbase + lane, 62u);
+        const uint32_t ys = (uint32_t)__shfl((int)segy, (int)wl), yn = (uint32_t)__shfl((int)segy, (int)wl + 1), xs = (uint32_t)__shfl((int)segx, (int)wl);
+        const uint32_t si = sg + lane;                                   // this lane's segment
+        const uint32_t ye = (si + 1 < nseg) ? yn : nsym, x = xs & 0x7FFFFFFFu, run = xs >> 31;
+        const bool needed = lane < 9u && si < nseg && (lane == 0u || ys < end);
+        const uint64_t need_m = __ballot(needed);
+        if (need_m & 0x100ull) return -1;                                // more than eight pieces
+        if ((need_m & (need_m + 1ull)) != 0ull) return 0;                // (not a prefix of the lanes: the records are out of order -- not here)
+        const uint32_t P = (uint32_t)__popcll(need_m);
+        const uint32_t lo_abs = max(ys, spos), hi_abs = min(ye, end);
+        bool bad = ye <= lo_abs;                                         // the piece holds none of the row (a hole, an empty record)
+        if (lane == 0u) bad = bad || spos < ys;
+        bad = bad || (run ? x >= ntok : x + (hi_abs - ys) > ntok);        // (a literal run past the end: the other path reports it)
+        if (__any(needed && bad)) return 0;
+        // (a piece's end is the next one's start -- or nsym behind the last record: the needed pieces reach the row's end by construction)
+        // (a run's value comes in the same kind of load as a literal vector -- the eight tokens that hold it, the last eight of the
+        // unit at most: two kinds of load into one register made the compiler wait for the first before it issued the second, six
+        // memory round trips a row)
+        const uint32_t xb = min(x, ntok - 8u), xsh = x - xb;
+        const uint32_t plo = lo_abs - spos, phi = needed ? hi_abs - spos : 0xFFFu;       // row positions (< 4096)
+        const uint32_t pa = run ? xb : x + spos - ys;                     // literal: the token of row position q is pa + q
+        const uint32_t pw = plo | (phi << 12) | ((run ? 2u + (xsh << 2) : 1u) << 24);
+        uint32_t pend[8];                                                // the pieces' ends, wave-uniform (0xFFF behind the last)
+#pragma unroll
+        for (int q = 0; q < 8; q++) pend[q] = (uint32_t)__builtin_amdgcn_readlane((int)phi, q);
+        auto piece_of = [&](uint32_t pos) -> uint32_t {                   // pieces that end at or in front of `pos`
+            uint32_t c = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) c += (pend[q] <= pos) ? 1u : 0u;
+            return c;
+        };
         uint32_t kind[NVJ], off[NVJ];
 #pragma unroll
-        for (int r = 0; r < NVJ; r++) { kind[r] = 0; off[r] = 0; }
-        const uint32_t bslot = lane >> 3, bk = lane & 7u;                 // eight lanes per boundary: the vector in which piece `bslot` ends
-        uint32_t ep = 0xFFFFFFFFu, bsrc = 0; bool bhave = false;
-        uint32_t P = 0;
-        {
-            uint32_t s = spos, i = sg;
-#pragma unroll 1
-            while (s < spos + to) {
-                if (i >= nseg) return 0;
-                const uint32_t ys = seg_y(i), ye = (i + 1 < nseg) ? seg_y(i + 1) : nsym, xs = seg_x(i), x = xs & 0x7FFFFFFFu;
-                if (s < ys || s >= ye) return 0;
-                const uint32_t hi_ = min(spos + to, ye), run = xs >> 31;
-                if (run) { if (x >= ntok) return 0; }
-                else if (x + (hi_ - ys) > ntok) return 0;                 // (a literal run past the end: the other path reports it)
-                const uint32_t plo = s - spos, phi = hi_ - spos, rel = x + spos - ys;   // literal: token of row position q = rel + q
-                const uint32_t r_lo = plo >> 9, r_hi = (phi - 1u) >> 9;
-                // (a run's value comes in the same kind of load as a literal vector -- the eight tokens that hold it, the last eight
-                // of the unit at most: two kinds of load into one register made the compiler wait for the first before it issued the
-                // second, six memory round trips a row)
-                const uint32_t xb = min(x, ntok - 8u), xsh = x - xb;
-#pragma unroll
-                for (int r = 0; r < NVJ; r++) {
-                    if ((uint32_t)r >= r_lo && (uint32_t)r <= r_hi) {        // (wave-uniform: a scalar branch)
-                        const uint32_t vlo = 8u * (lane + 64u * (uint32_t)r);
-                        const bool inside = vlo >= plo && vlo + 8u <= phi;
-                        kind[r] = inside ? (run ? 2u + (xsh << 2) : 1u) : kind[r];
-                        off[r] = inside ? (run ? xb : rel + vlo) : off[r];
-                    }
-                }
-                if (P == bslot) ep = ((phi & 7u) != 0u) ? (phi & ~7u) + bk : 0xFFFFFFFFu;
-                if (ep != 0xFFFFFFFFu && ep >= plo && ep < phi) { bsrc = run ? x : rel + ep; bhave = true; }
-                s = hi_; i++;
-                if (++P > 8) return -1;
-            }
+        for (int r = 0; r < NVJ; r++) {
+            const uint32_t vlo = 8u * (lane + 64u * (uint32_t)r), pi = min(piece_of(vlo), 63u);
+            const uint32_t w = (uint32_t)__shfl((int)pw, (int)pi), av = (uint32_t)__shfl((int)pa, (int)pi);
+            const bool inside = pi < P && vlo >= (w & 0xFFFu) && vlo + 8u <= ((w >> 12) & 0xFFFu);
+            const uint32_t kd = w >> 24;
+            kind[r] = inside ? kd : 0u;
+            off[r] = (kd & 2u) ? av : av + vlo;
         }
-        // (an element in front of its slot's piece -- a piece that begins and ends inside one vector -- has not been seen: that row
-        // goes piece by piece)
-        if (__any(ep != 0xFFFFFFFFu && ep < to && !bhave)) return -1;
-        if (ep >= to) bhave = false;
+        // the vector in which piece `bslot` ends, element by element (the row's last, partial vector is the last piece's)
+        const uint32_t bslot = lane >> 3, bk = lane & 7u;
+        const uint32_t bend = ((uint32_t)__shfl((int)pw, (int)bslot) >> 12) & 0xFFFu;
+        uint32_t ep = 0xFFFFFFFFu, bsrc = 0; bool bhave = false;
+        if (bslot < P && (bend & 7u) != 0u) ep = (bend & ~7u) + bk;
+        {
+            const uint32_t pe = min(piece_of(min(ep, 0xFFEu)), 63u);
+            const uint32_t w = (uint32_t)__shfl((int)pw, (int)pe), av = (uint32_t)__shfl((int)pa, (int)pe);
+            bhave = ep < to && pe < P;
+            bsrc = (w & (2u << 24)) ? av + (w >> 26) : av + ep;           // a run: its value's own token
+        }
         nx_kind = 0;
 #pragma unroll
         for (int r = 0; r < NVJ; r++) {
