@@ -127,9 +127,11 @@ def _share_torch_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and ask for it by
     the bare name, which the loader does not match against /opt/rocm's copy once libmic_hip.so has pulled that in: a process that
     loads this library first and imports torch afterwards ends up with two runtimes, and the second one finds no GPU.  When a torch
-    install is present its copy is loaded first (by path, without importing torch), so either import order gives one runtime."""
+    install is present its copy is loaded first (by path, without importing torch), so either import order gives one runtime.
+    MIC_HIP_NO_TORCH_PRELOAD=1 turns the preload off (a process that never imports torch, or whose torch wheel is built against another
+    HIP major version than libmic_hip.so: binding this library to that runtime would be an ABI mismatch nobody reports)."""
     import importlib.util
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("MIC_HIP_NO_TORCH_PRELOAD") == "1":
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -141,8 +143,26 @@ def _share_torch_hip_runtime():
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        except OSError as e:
+            import warnings
+            warnings.warn(f"mic_hip: could not preload torch's HIP runtime ({cand}: {e}); importing torch after this library may "
+                          "leave the process with two runtimes", RuntimeWarning)
+
+
+def _check_one_hip_runtime():
+    """After libmic_hip.so is mapped: exactly one libamdhip64 in the process, or say so loudly (two runtimes = the second finds no
+    GPU; see _share_torch_hip_runtime)."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+    except OSError:
+        return
+    real = {os.path.realpath(q) for q in paths}
+    if len(real) > 1:
+        import warnings
+        warnings.warn("mic_hip: more than one HIP runtime is mapped into this process: " + ", ".join(sorted(real)) +
+                      " -- device calls of the one loaded second will fail; import torch before this package, or set "
+                      "MIC_HIP_NO_TORCH_PRELOAD=1 and never import torch", RuntimeWarning)
 
 
 def lib() -> C.CDLL:
@@ -155,6 +175,7 @@ def lib() -> C.CDLL:
                           "(or __graft_entry__.build()); there is no CPU fallback")
     _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    _check_one_hip_runtime()
     L.mic_hip_device_name.restype = C.c_char_p
     L.mic_hip_version.restype = C.c_char_p
     L.mic_hip_session_stream.restype = C.c_void_p
@@ -448,14 +469,20 @@ def host_alloc(nbytes: int, dtype=np.uint8) -> np.ndarray:
         raise MicError(MIC_ERR_NOMEM, "host_alloc")
     buf = (C.c_uint8 * nbytes).from_address(p)
     a = np.frombuffer(buf, dtype=np.uint8).view(dtype)
-    _PINNED[a.ctypes.data] = p
+    _PINNED[p] = nbytes
     return a
 
 
 def host_free(a: np.ndarray) -> None:
-    p = _PINNED.pop(a.ctypes.data, None)
-    if p:
-        lib().mic_hip_host_free(p)
+    """Frees the pinned allocation `a` lies in -- `a` itself, or any view of it (a reshape, a slice: the allocation is found by
+    address).  A buffer that host_alloc did not hand out raises instead of leaking quietly."""
+    addr = int(a.ctypes.data)
+    for p, n in _PINNED.items():
+        if p <= addr < p + max(n, 1):
+            del _PINNED[p]
+            lib().mic_hip_host_free(p)
+            return
+    raise ValueError("host_free: not (a view of) a buffer from host_alloc, or freed already")
 
 
 _PINNED = {}

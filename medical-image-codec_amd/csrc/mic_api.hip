@@ -101,13 +101,22 @@ std::vector<int> default_devices() { std::lock_guard<std::mutex> lk(g_mu); retur
 // already holds, or -- never more than a quarter of the device -- half of what is free right now, so that several sessions on one GPU
 // (the pool, explicit sessions, the caller's own tensors) do not each grow towards the same ceiling.  MIC_HIP_WS_BUDGET_MB overrides it
 // (tests walk the sub-batch loops with small inputs).
+// Sessions of this thread's device that are out on lease right now (this thread's included; at least 1): each of them reads the same
+// free-memory figure at about the same time, so each may plan with its share of it only.
+static size_t leased_here() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int dev = tl_default ? tl_default->device : g_device;
+    auto it = g_pools.find(dev);
+    if (it == g_pools.end()) return 1;
+    return (size_t)std::max(1, it->second.made - (int)it->second.free_.size());
+}
 size_t workspace_budget() {
     static const long env_mb = [] { const char *e = getenv("MIC_HIP_WS_BUDGET_MB"); return e ? atol(e) : 0L; }();
     if (env_mb > 0) return (size_t)env_mb << 20;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { tot = (size_t)96 << 30; fr = tot / 2; }
     const size_t held = tl_default ? tl_default->reserved_bytes() : 0;
-    return std::max<size_t>(std::max<size_t>(held, std::min<size_t>(tot / 4, fr / 2)), (size_t)1 << 30);
+    return std::max<size_t>(std::max<size_t>(held, std::min<size_t>(tot / 4, fr / 2 / leased_here())), (size_t)1 << 30);
 }
 
 // ---- encode -------------------------------------------------------------------------------
@@ -329,12 +338,13 @@ size_t unit_ws_bytes_tier(size_t px, int tier) {
 size_t unit_ws_bytes(size_t px) { return unit_ws_bytes_tier(px, 2); }      // (the paths that lay their units out themselves: tier 2)
 // Units of px pixels (x `mult` slabs each) a sub-batch of the tiered unit codec may hold: tier-1 slabs under the workspace ceiling --
 // and tier-2 slabs, should the batch have to run again, inside nine tenths of what the device can give this session.
-size_t batch_units_for(size_t px, size_t mult) {
-    const size_t n1 = workspace_budget() / (mult * unit_ws_bytes_tier(px, 1));
+// `extra`: bytes per unit the caller holds beside the slabs (the host path's staging halves).
+size_t batch_units_for(size_t px, size_t mult, size_t extra) {
+    const size_t n1 = workspace_budget() / (mult * (unit_ws_bytes_tier(px, 1) + extra));
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = (size_t)32 << 30; }
     const size_t held = tl_default ? tl_default->reserved_bytes() : 0;
-    const size_t n2 = (size_t)((double)(fr + held) * 0.9) / (mult * unit_ws_bytes_tier(px, 2));
+    const size_t n2 = (size_t)((double)(fr / leased_here() + held) * 0.9) / (mult * (unit_ws_bytes_tier(px, 2) + extra));
     return std::max<size_t>(1, std::min(n1, n2));
 }
 

@@ -90,11 +90,19 @@ private:
         s.busy = false;
         s.req->done(ok);
     }
+    // a slot whose transfer has completed is retired at once -- its request is signalled (and a pageable download copied out) before
+    // the worker takes more work: waiting for the slot's next use held a request's last chunks back for two more submissions, and
+    // with callers on several devices for as long as the other device's request kept the worker fed
+    static void retire_finished(Slot &s) {
+        if (s.busy && hipEventQuery(s.ev) == hipSuccess) retire(s);
+        else (void)hipGetLastError();                  // (hipErrorNotReady is not an error to keep)
+    }
     void run(int first) {
         std::vector<PerDev> devs;
         for (;;) {
             IoChunk c;
             bool have = false;
+            for (auto &d : devs) { retire_finished(d.slot[0]); retire_finished(d.slot[1]); }
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 bool inflight = false;
@@ -202,7 +210,7 @@ int next_cut(const std::vector<U> &units, int i0, size_t target) {
     while (i1 < n) {
         const size_t px = (size_t)units[(size_t)i1].w * (size_t)units[(size_t)i1].h;
         const size_t mp = std::max(max_px, px);
-        if (mp != max_px || cap == 0) cap = batch_units_for(mp, 1);
+        if (mp != max_px || cap == 0) cap = batch_units_for(mp, 1, 12 * mp);   // (+ the staging: two halves each of the pixels, the streams, the packed buffer)
         if (i1 > i0 && ((size_t)(i1 - i0 + 1) > cap || (size_t)(i1 - i0) >= target || i1 - i0 >= 65535)) break;
         max_px = mp; i1++;
     }

@@ -292,7 +292,7 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_base, cons
 int session_decode_finish(mic_hip_session *s, int32_t *h_status);
 size_t unit_ws_bytes(size_t px);
 size_t unit_ws_bytes_tier(size_t px, int tier);
-size_t batch_units_for(size_t px, size_t mult);   // units per sub-batch of the tiered unit codec (mic_api.hip)
+size_t batch_units_for(size_t px, size_t mult, size_t extra = 0);   // units per sub-batch of the tiered unit codec (mic_api.hip)
 // MIC2 temporal pipeline (mic_temporal.hip)
 int mic2_temporal_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
                            uint8_t *out, size_t out_cap, size_t *out_len);

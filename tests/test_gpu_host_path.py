@@ -69,7 +69,11 @@ def test_pinned_buffers_take_the_direct_path(mic, mico, synth, gpu_ready):
         assert st == 0 and np.array_equal(px, img)
         mic.host_free(back)
     finally:
-        mic.host_free(src); mic.host_free(dst)
+        mic.host_free(src[1:, 3:]); mic.host_free(dst)                   # (any view names its allocation: ADVICE r3)
+    with pytest.raises(ValueError):
+        mic.host_free(src)                                               # freed already
+    with pytest.raises(ValueError):
+        mic.host_free(np.zeros(16, dtype=np.uint8))                      # never pinned
 
 
 def test_sub_batch_pipeline_under_a_small_workspace(mic, mico, synth):
