@@ -143,11 +143,20 @@ static int encode_enqueue_tier(mic_hip_session *s, const uint16_t *d_pixels, con
     { const int urc = s->h_units.upload(s->units.p, (size_t)n, s->stream); if (urc) return urc; }
     if ((rc = s->prepare_hist(n))) return rc;
     s->timer.reset(s->stream);
+    // The encoder's classes: what the session's last batches used, plus what the HOST can tell -- the two big instances always (a
+    // two-state unit whose attempt fails is handed to the wide one; a miss there is the serial encoder, 0.8 s for an XR batch:
+    // tools/mask_miss.py), the one-wave instances when a unit is small enough for them, the tableLog 14-16 ones when a unit is deep
+    // enough to have such an alphabet.  What is left to memory alone costs ~5 us a launch when it is wrong the other way.
+    uint32_t enc_hint = MIC_ENC_CLS_NARROW2 | MIC_ENC_CLS_WIDE;
+    for (int i = 0; i < n; i++) {
+        if ((size_t)units[i].width * (size_t)units[i].height <= 131072u) enc_hint |= MIC_ENC_CLS_SMALL12 | MIC_ENC_CLS_SMALL13;
+        if (units[i].max_value >= 2048u) enc_hint |= MIC_ENC_CLS_TL14 | MIC_ENC_CLS_TL15 | MIC_ENC_CLS_TL16;
+    }
     mic_launch_encode((MicUnit *)s->units.p, n, s->stream, s->variant | MIC_VARIANT_FRAMES | (any_grad ? MIC_VARIANT_GRAD : 0) | (narrow ? MIC_VARIANT_NARROW : 0), &s->timer,
-                      s->enc_classes.mask());
-    s->learn_encode = true;
+                      s->enc_classes.mask() | enc_hint);
     if (hipGetLastError() != hipSuccess) { s->hist_unknown(); return MIC_ERR_DEVICE; }
     s->begin_chain(n);
+    s->learn_encode = true;                                              // (behind begin_chain, which clears it: the masks were never learned)
     // Compaction and the read-back of the results ride behind the chain, so that session_encode_finish is ONE synchronisation (round 3:
     // descriptors down, a synchronisation, sizes summed on the host, scan + pack launched, a second synchronisation -- 86 us of idle
     // device between the chain and the pack of every call).  The packed buffer is sized from what the session's last batch needed;
@@ -254,7 +263,7 @@ int session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t 
     s->pack_queued = false;
     s->pack_hint = (size_t)total;
     if (!packed_already) {                         // a caller that launched its own chain, or a batch larger than the session's last
-        int rc = s->packed.reserve((size_t)total + 16);
+        int rc = s->packed.reserve((size_t)total + (size_t)total / 8 + ((size_t)64 << 10));   // (what the next enqueue of such a batch will ask for: no second reallocation)
         if (rc) return rc;
         mic_launch_pack((const MicUnit *)s->units.p, n, (uint64_t *)s->offsets.p, (uint8_t *)s->packed.p, (uint64_t)s->packed.cap, s->stream, nullptr);
         HIP_TRY(hipGetLastError());
@@ -312,9 +321,9 @@ int session_decode_enqueue_spans(mic_hip_session *s, const uint8_t *d_blobs, con
     s->timer.reset(s->stream);
     mic_launch_decode((MicUnit *)s->units.p, n, s->stream, s->variant | (any_grad ? MIC_VARIANT_GRAD : 0), &s->timer, (int *)s->cls.p, rows_kmask,
                       s->dec_classes.mask());
-    s->learn_decode = true;
     HIP_TRY(hipGetLastError());
     s->begin_chain(n);
+    s->learn_decode = true;
     HIP_TRY(hipMemcpyAsync(s->h_units.data(), s->units.p, sizeof(MicUnit) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
     s->readback_queued = true;
     return MIC_OK;

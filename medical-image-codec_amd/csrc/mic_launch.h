@@ -55,6 +55,10 @@ struct MicTimer {
 // decode of a PICS batch, 0.2 ms).  What the HOST knows (widths, modes) it says outright; what only the streams know (flavour,
 // tableLog) a session remembers from its last batches -- the catch-all kernels (k_dec_tans_gl / _serial, k_enc_tans_serial) are
 // always launched and take whatever a stale mask leaves, so a wrong guess costs time, never correctness.  All ones: launch everything.
+// What a wrong guess costs (tools/mask_miss.py, 2304 XR strips, a session that had only seen two-state batches meets a four-state
+// one): decode 69 ms once instead of 15.5 (k_dec_tans_gl takes the batch; the next call has learned the class).  On the encode side
+// the same miss was 0.77 s through the serial encoder, so there the host's own knowledge is OR-ed in (mic_api.hip: the two big
+// instances always, the small and deep ones by unit size and depth) and memory only decides what the host cannot know.
 #define MIC_ENC_CLS_NARROW2 0x01u       // k_enc_tans_wg<13, 512, .., 1>: two states, records in LDS
 #define MIC_ENC_CLS_WIDE    0x02u       // k_enc_tans_wg<13, 512, .., 2>
 #define MIC_ENC_CLS_SMALL12 0x04u       // one-wave instances
