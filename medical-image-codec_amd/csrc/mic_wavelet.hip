@@ -489,7 +489,10 @@ __global__ void __launch_bounds__(1024) k_wv_symbols_par(MicUnit *units, const i
         else for (int k = 0; k < 8; k++) if (i0 + (uint32_t)k < n) sym[i0 + k] = (uint16_t)(w8[k >> 1] >> (16 * (k & 1)));
 #pragma unroll
         for (int dd = 32; dd > 0; dd >>= 1) zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, dd));
-        if (lane == 0 && zmax) atomicMax(&u.wv_zmax, zmax);
+        // (one address per frame: an atomic per wave was 59 k atomics in a row on it.  The maximum only grows, so a wave whose own is
+        // not above what the frame has already -- nearly every wave after the first few -- has nothing to say; a stale read only costs
+        // an atomic that changes nothing)
+        if (lane == 0 && zmax > __hip_atomic_load(&u.wv_zmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&u.wv_zmax, zmax);
         if (wide) u.wv_slow = 1;
     }
 }
