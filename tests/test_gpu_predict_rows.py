@@ -86,3 +86,36 @@ def test_rows_predictor_wrapping_streams_agree_with_the_oracle(mic, mico, synth,
                     differing_from_clean += 1
                 checked += 1
     assert checked > 40 and differing_from_clean > 20
+
+
+def test_wide_frames_with_damaged_tokens_agree_with_the_oracle(mic, mico, synth, gpu_ready):
+    """What test_gpu_parity's damaged-token test does, at the widths the fused tokens-to-pixels kernel takes (k_dec_rows_tok: rows
+    assembled from the header walk's segments): zero counts, headers that point past the end or into the middle of a chunk, streams
+    that stop early -- coded again so that the entropy stage accepts them.  The kernel must decline what it cannot take for certain
+    (the two-kernel path then reports the reference's error) and make the oracle's pixels of everything else."""
+    rng = np.random.default_rng(17)
+    total = decodable = 0
+    for seed, noise, (h, w) in ((3, 2.0, (20, 1100)), (4, 60.0, (12, 2577)), (5, 10.0, (16, 1700)), (6, 167.0, (9, 2688)), (7, 4.0, (30, 1009))):
+        img = synth.xr_like(cols=w, rows=h, depth=12, seed=seed, noise=noise)
+        tok = mico.delta_rle_compress(img, 4095)
+        for k in range(48):
+            t = tok.copy()
+            for _ in range(int(rng.integers(1, 5))):
+                i = int(rng.integers(1, t.size))
+                t[i] = (0, 1, 2, int(t[0]), int(t[0]) // 2 + 1, int(rng.integers(0, int(t[0]) + 1)))[int(rng.integers(0, 6))]
+            if k % 8 == 2:
+                t = t[: int(rng.integers(3, t.size))]
+            rc, stream = mico.fse_compress(t, 2)
+            if rc:
+                continue
+            rc_o, want = mico.decompress_single_frame(stream, w, h)
+            try:
+                got, rc_g = mic.decompress_single_frame(stream, w, h), 0
+            except mic.MicError as e:
+                got, rc_g = None, e.code
+            assert (rc_g == 0) == (rc_o == 0), (seed, k, rc_g, rc_o)
+            if rc_o == 0:
+                assert np.array_equal(got, want), (seed, k, int(np.count_nonzero(got != want)))
+                decodable += 1
+            total += 1
+    assert total > 100 and decodable > 30 and total - decodable > 20
