@@ -216,8 +216,28 @@ static int finish_units(mic_hip_session *s, int n) {
     return MIC_OK;
 }
 
+// The tier is sticky, not permanent: a session that one escape-heavy (or 16-bit) batch sent to the worst-case slabs -- 42 bytes a pixel
+// -- goes back to the ordinary ones when kTierCalm batches in a row would have fitted them (every unit's tokens, segments, alphabet
+// and table inside the tier-1 capacities), and ensure() then returns the large slabs' memory.  Called with the descriptors read back.
+static void tier_review(mic_hip_session *s, int n) {
+    if (!s->force_big || s->tier != 2) return;
+    bool fits = true;
+    const size_t ts1 = tab_syms_tier(1);
+    for (int i = 0; i < n && fits; i++) {
+        const MicUnit &u = s->h_units[(size_t)i];
+        if (u.mode != 0) { fits = false; break; }                       // (units laid out by the wavelet / temporal paths: theirs to decide)
+        const size_t px = (size_t)std::max(u.w, 0) * (size_t)std::max(u.h, 0);
+        const size_t ntok = std::max<size_t>(u.ntok, u.count);
+        fits = u.status == MICD_OK && ntok + 64 <= tok_cap_tier(px, 1) && (size_t)u.nseg + 8 <= seg_cap_tier(px, 1) &&
+               u.symbol_len <= ts1 && u.table_log <= 13 && u.max_value < (1u << 13);
+    }
+    if (!fits) { s->calm_batches = 0; return; }
+    if (++s->calm_batches >= mic_hip_session::kTierCalm) { s->force_big = false; s->calm_batches = 0; }
+}
+
 // what the batch just finished tells the next one (mic_launch.h: launch masks)
 static void learn_classes(mic_hip_session *s, int n) {
+    tier_review(s, n);
     if (s->learn_decode) {
         uint32_t seen = 0;
         for (int i = 0; i < n; i++) {

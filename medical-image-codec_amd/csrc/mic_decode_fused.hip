@@ -252,14 +252,25 @@ __global__ void __launch_bounds__(256, 3) k_dec_rows_tok(MicUnit *units, int n_u
 #pragma unroll
         for (int q = 0; q < KD; q++) sb[lane * KD + q] = tp[q];
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        // (the row's vectors come out of LDS three at a time, ONE wait for the three, then their stores: left to itself the compiler
+        // sinks every read into its store's branch -- seven LDS round trips in a row, one behind the other)
 #pragma unroll
-        for (int j = 0; j < NVJ; j++) {
-            const uint32_t i = lane + 64u * (uint32_t)j;
-            const uint4 v = *(const uint4 *)(sb + 4 * min(i, 8u * K - 1u));
-            if (i < nfull) *(__attribute__((address_space(1))) RfQ *)((rf_gu8)(px + ps) + 1024 * j + voff) = rf_v4{v.x, v.y, v.z, v.w};
+        for (int j0 = 0; j0 < NVJ; j0 += 3) {
+            uint4 v[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (j0 + t < NVJ) v[t] = *(const uint4 *)(sb + 4 * min(lane + 64u * (uint32_t)(j0 + t), 8u * K - 1u));
+            const uint32_t tv = (j0 + 3 >= NVJ && lane < ntail) ? (uint32_t)sb16[8 * nfull + lane] : 0u;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (j0 + t < NVJ) asm volatile("" : "+v"(v[t].x), "+v"(v[t].y), "+v"(v[t].z), "+v"(v[t].w));
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int j = j0 + t;
+                if (j < NVJ && lane + 64u * (uint32_t)j < nfull)
+                    *(__attribute__((address_space(1))) RfQ *)((rf_gu8)(px + ps) + 1024 * j + voff) = rf_v4{v[t].x, v[t].y, v[t].z, v[t].w};
+            }
+            if (j0 + 3 >= NVJ && lane < ntail) px[ps + 8 * nfull + lane] = (uint16_t)tv;
         }
-        if (lane < ntail) px[ps + 8 * nfull + lane] = sb16[8 * nfull + lane];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
     };
 
 #ifdef RF_STATS     // diagnostic build: rows by path and shader-clock ticks by phase, in u.dbg (tools/time_fused.py)

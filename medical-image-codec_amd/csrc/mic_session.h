@@ -134,7 +134,9 @@ struct mic_hip_session {
     int device = 0;                         // the HIP device this session's stream and workspace live on (mic_hip_session_create_on)
     int max_units = 0; size_t max_px = 0;   // shape of the current workspace layout (see ensure)
     int tier = 2;                           // tier of the current layout
-    bool force_big = false;                 // a batch of this session needed tier 2: later ones start there (sticky)
+    bool force_big = false;                 // a batch of this session needed tier 2: later ones start there ...
+    int calm_batches = 0;                   // ... until kTierCalm batches in a row would have fitted tier 1 (tier_review, mic_api.hip):
+    static constexpr int kTierCalm = 8;     //     the session goes back to the small slabs and gives the large ones' memory back
     // what a tier-1 launch chain needs to be run again in tier 2 (session_*_finish)
     struct Retry { int kind = 0; const void *d_in = nullptr; void *d_out = nullptr; std::vector<mic_hip_unit> units; std::vector<uint64_t> begins, ends; } retry;
     hipStream_t stream = nullptr;
@@ -196,7 +198,13 @@ struct mic_hip_session {
         // From here on the layout is in flux: a reservation that fails half way (DevBuf::reserve frees before it allocates) must not
         // leave the old shape key standing over new strides and freed slabs -- the next call of the old shape would take the early
         // return above and hand the kernels null or short slabs.  The key is cleared first and set again only when every slab stands.
+        const bool back_to_small = tier == 2 && want_tier == 1;         // (only tier_review sends a session that way)
         max_units = 0; max_px = 0; tier = 0;
+        if (back_to_small) {                                            // the worst-case slabs go back to the device: reserve() only ever grows
+            DevBuf *slabs[] = { &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &seg, &sym, &flags };
+            for (DevBuf *b : slabs) b->release();
+            hist_unknown();
+        }
         int nn = n; size_t pp = px;
         const size_t tokc = tok_cap_tier(pp, want_tier), ts = tab_syms_tier(want_tier);
         const size_t tok_s = align_up(tokc * 2, 256);
