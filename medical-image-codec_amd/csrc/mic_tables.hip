@@ -564,6 +564,9 @@ __global__ void __launch_bounds__(64) k_dec_parse(MicUnit *units) {
                 off = 6;
                 if (count > u.tok_cap) { rc = u.tier == 1 ? MICD_INT_GROW : MICD_ERR_CORRUPT; break; }   // (tier 1: a small token slab; tier 2 decides)
             }
+            // (a table of more than 8192 states is the BIG class's whatever its alphabet -- the table slabs of this class's tier hold
+            // 8192: a WaveletV2 stream, tableLog 16, was parsed half way here, 8192 of its ~16 k symbols, before it was handed over)
+            if (!BIG && off < len && (uint32_t)(s_in[off] & 0xF) + MIC_MIN_TABLELOG > 13u) { rc = MICD_ERR_UNSUPPORTED; break; }
             // Parse from the staged bytes when that is certain to be identical: the whole blob is staged, or the
             // header ends well inside the stage; otherwise from HBM.
             // (the window reader may look 8 bytes past the bytes it is given: the stage is DP_STAGE + 16 bytes long)
