@@ -664,6 +664,40 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     }
 }
 
+// States -> symbols for the units k_dec_translate has no header walk to do for (a whole WaveletV2 frame: one unit of millions of
+// tokens, its headers walked in parts by k_rle_walk_parts) and whose table is the 128 KiB one: the table takes a CU's LDS, so a unit has
+// the CU to itself whatever the kernel -- and then three translating waves behind a barrier per 1536 tokens leave it idle (2.0 ms for
+// 256 CR frames).  Here: sixteen waves, no tile, no barrier; a wave takes every sixteenth block of 512 tokens.
+#define TRW_THREADS 1024
+__global__ void __launch_bounds__(TRW_THREADS) k_dec_translate_wide(MicUnit *units) {
+    MicUnit &u = units[blockIdx.x];
+    if (u.status != MICD_OK || u.walk_ok != 2 || u.table_log <= 13) return;
+    if (!(u.mode == 1 && u.walk_mode == 1 && u.seg != nullptr)) return;     // (frames and bare streams: k_dec_translate<16>, which walks)
+    __shared__ uint16_t s_sym[1 << 16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t size = 1u << u.table_log, ntok = u.ntok, smask = size - 1;
+    {
+        const uint32_t *src = (const uint32_t *)u.tab_sym;
+        for (uint32_t i = tid; i < size / 2; i += TRW_THREADS) ((uint32_t *)s_sym)[i] = src[i];
+    }
+    __syncthreads();
+    uint16_t *tok = u.tok;
+    typedef uint32_t tr_v4 __attribute__((ext_vector_type(4)));
+    const uint32_t nvec = ntok / 8;
+    for (uint32_t i = tid; i < nvec; i += TRW_THREADS) {
+        const tr_v4 v = __builtin_nontemporal_load((const tr_v4 *)(tok + 8 * i));
+        tr_v4 o;
+        o.x = (uint32_t)s_sym[v.x & smask] | ((uint32_t)s_sym[(v.x >> 16) & smask] << 16);
+        o.y = (uint32_t)s_sym[v.y & smask] | ((uint32_t)s_sym[(v.y >> 16) & smask] << 16);
+        o.z = (uint32_t)s_sym[v.z & smask] | ((uint32_t)s_sym[(v.z >> 16) & smask] << 16);
+        o.w = (uint32_t)s_sym[v.w & smask] | ((uint32_t)s_sym[(v.w >> 16) & smask] << 16);
+        *(tr_v4 *)(tok + 8 * i) = o;
+    }
+    for (uint32_t i = 8 * nvec + tid; i < ntok; i += TRW_THREADS) tok[i] = s_sym[tok[i] & smask];
+    __syncthreads();                                                        // (every state of the unit has been read as a state)
+    if (tid == 0) u.walk_ok = 3u;                                           // translated; the headers are k_rle_walk_parts's
+}
+
 template <int N, bool ZB, int TL>
 static void launch_ls_class(MicUnit *d_units, int n, const int *d_list, const int *d_count, hipStream_t stream, uint32_t cls_mask) {
     constexpr int cls = (TL <= 12 ? 4 : TL - 13) * 6 + (N == 2 ? 0 : N == 4 ? 2 : 4) + (ZB ? 1 : 0);
@@ -702,5 +736,8 @@ void mic_launch_dec_tans_ls(MicUnit *d_units, int n, int *d_list, int *d_count, 
     if (t) t->mark("k_dec_translate");
     // classes 0-5: tableLog 13, 24-29: tableLog <= 12 -> the 16 KiB symbol table; 6-23: tableLog 14..16 -> the 128 KiB one
     if (cls_mask & 0x3F00003Fu) hipLaunchKernelGGL(k_dec_translate<13>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
-    if (cls_mask & 0x00FFFFC0u) hipLaunchKernelGGL(k_dec_translate<16>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    if (cls_mask & 0x00FFFFC0u) {
+        hipLaunchKernelGGL(k_dec_translate_wide, dim3((unsigned)n), dim3(TRW_THREADS), 0, stream, d_units);   // (marks its units walk_ok 3: the next launch skips them)
+        hipLaunchKernelGGL(k_dec_translate<16>, dim3((unsigned)n), dim3(TR_THREADS), 0, stream, d_units);
+    }
 }

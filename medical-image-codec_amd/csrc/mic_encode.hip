@@ -780,6 +780,9 @@ __global__ void __launch_bounds__(64) k_enc_tans_serial(MicUnit *units) {
 // LDS: stateTable as u16 (state - 2^tl).  grid = units, block = 1024, dynamic LDS = 2 << tl.
 #define TE_THREADS 512              // two groups per CU (128 VGPRs each): the fix-up stalls of one overlap the other's work
 #define TE_WAVES 8
+#ifndef TE_THREADS16
+#define TE_THREADS16 1024         // threads of the tableLog-16 instance: its 128 KiB table leaves a CU one group whatever its size
+#endif
 #define TE_BLK 64                 // the largest block a walk reads at a time, in tokens (te_encode: BLK)
 #ifndef TE_WARM_TOK
 #define TE_WARM_TOK 128           // tokens of the predecessor's range a thread walks first (a multiple of 64)
@@ -1355,7 +1358,7 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<13, TE_THREADS, TE_TT_SYMS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_enc_tans_wg<16, TE_THREADS16, TE_TT_SYMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     });
     const int es = (variant & MIC_VARIANT_NARROW) ? 2 : 8;                      // widest flavour in the batch -> end-state area
     const unsigned eb = TE_THREADS * (unsigned)es * 2u, eb1 = 64u * (unsigned)es * 2u;
@@ -1369,7 +1372,7 @@ void mic_launch_encode(MicUnit *d_units, int n, hipStream_t stream, int variant,
     if (t) t->mark("k_enc_tans_wg<other classes>");
     if (enc_mask & MIC_ENC_CLS_TL14) hipLaunchKernelGGL((k_enc_tans_wg<14, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 14) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
     if (enc_mask & MIC_ENC_CLS_TL15) hipLaunchKernelGGL((k_enc_tans_wg<15, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 15) + TE_TT_SYMS * 8 + eb, stream, d_units, es);
-    if (enc_mask & MIC_ENC_CLS_TL16) hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS), (2u << 16) + eb, stream, d_units, es);
+    if (enc_mask & MIC_ENC_CLS_TL16) hipLaunchKernelGGL((k_enc_tans_wg<16, TE_THREADS16, TE_TT_SYMS>), dim3(n), dim3(TE_THREADS16), (2u << 16) + TE_THREADS16 * (unsigned)es * 2u, stream, d_units, es);
     if (t) t->mark("k_enc_tans_serial");
     hipLaunchKernelGGL(k_enc_tans_serial, dim3(n), dim3(64), 0, stream, d_units);
     if (t) t->mark("k_enc_hist_clean");
