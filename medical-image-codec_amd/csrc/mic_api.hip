@@ -232,7 +232,7 @@ static void tier_review(mic_hip_session *s, int n) {
                u.symbol_len <= ts1 && u.table_log <= 13 && u.max_value < (1u << 13);
     }
     if (!fits) { s->calm_batches = 0; return; }
-    if (++s->calm_batches >= mic_hip_session::kTierCalm) { s->force_big = false; s->calm_batches = 0; }
+    if (++s->calm_batches >= mic_hip_session::kTierCalm) { s->force_big = false; s->calm_batches = 0; s->shrink_pending = true; }
 }
 
 // what the batch just finished tells the next one (mic_launch.h: launch masks)

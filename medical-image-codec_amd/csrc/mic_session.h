@@ -136,6 +136,7 @@ struct mic_hip_session {
     int tier = 2;                           // tier of the current layout
     bool force_big = false;                 // a batch of this session needed tier 2: later ones start there ...
     int calm_batches = 0;                   // ... until kTierCalm batches in a row would have fitted tier 1 (tier_review, mic_api.hip):
+    bool shrink_pending = false;            //     set there; the next tier-1 layout then starts from released slabs
     static constexpr int kTierCalm = 8;     //     the session goes back to the small slabs and gives the large ones' memory back
     // what a tier-1 launch chain needs to be run again in tier 2 (session_*_finish)
     struct Retry { int kind = 0; const void *d_in = nullptr; void *d_out = nullptr; std::vector<mic_hip_unit> units; std::vector<uint64_t> begins, ends; } retry;
@@ -198,7 +199,10 @@ struct mic_hip_session {
         // From here on the layout is in flux: a reservation that fails half way (DevBuf::reserve frees before it allocates) must not
         // leave the old shape key standing over new strides and freed slabs -- the next call of the old shape would take the early
         // return above and hand the kernels null or short slabs.  The key is cleared first and set again only when every slab stands.
-        const bool back_to_small = tier == 2 && want_tier == 1;         // (only tier_review sends a session that way)
+        // (a session also goes from a tier-2 layout to a tier-1 one when its caller alternates between paths -- a WaveletV2 or pyramid
+        // call lays out in tier 2, the unit codec in tier 1: that is no reason to give memory back, it would be bought again at once)
+        const bool back_to_small = shrink_pending && want_tier == 1;
+        if (back_to_small) shrink_pending = false;
         max_units = 0; max_px = 0; tier = 0;
         if (back_to_small) {                                            // the worst-case slabs go back to the device: reserve() only ever grows
             DevBuf *slabs[] = { &tok, &hist, &norm, &tt_nb, &tt_find, &state_tab, &tab_sym, &cumul, &blob, &seg, &sym, &flags };
