@@ -8,16 +8,18 @@
 // order, which is the order the token stream produces it in, so a wave can make each row's symbols itself:
 //   * the header walk has left the unit's RLE segments {payload position | run flag, first symbol} in HBM (k_dec_translate); a row
 //     of W pixels is W consecutive symbols (more when it holds escapes): a handful of pieces of those segments -- a literal chunk is
-//     up to midCount symbols long, a run as long as it likes.  The wave copies a literal piece from the token stream into an LDS
-//     row buffer with 16-byte loads at whatever 2-byte offset the piece starts (the destination side is what is aligned) and fills
-//     a run piece with its value; piece ends are written element-wise.  A window of 64 segment records lives in two registers.
+//     up to midCount symbols long, a run as long as it likes.  A window of 64 segment records lives in two registers; a row's
+//     pieces (up to eight) are described one per lane, every 16-byte vector of the LDS row finds the piece it lies in and is loaded
+//     from the token stream at whatever 2-byte offset that is (the destination side is what is aligned; a run's value comes in
+//     the same kind of load and is spread in registers), the vectors a piece ends in are put together element by element, eight
+//     lanes apiece.  The loads of a row are issued one row ahead.  Rows of more pieces are copied piece by piece (assemble).
 //   * a symbol equal to the delimiter is an escape marker unless it is the payload of one (marker[i] = isDelim[i] & !marker[i-1]);
 //     a row without a delimiter -- almost every row -- is its symbols as they stand.  A row with one takes the marker scan of
 //     k_dec_pixels_wg at wave scale (per-lane transition functions, composed across the lanes, pixels scattered into a second LDS
 //     row with their raw bits) over up to 512 symbols more than the row has pixels.
 //   * then the predictor, and the row leaves through the same LDS buffer in 1 KiB runs (mic_decode_rows.hip).
-// Whatever is out of the ordinary -- a literal piece that points past the stream, symbols that run out, a segment slab that was
-// full, more than sixteen pieces per row on average -- is NOT handled here: the unit is left as it was (walk_ok stays 1) and the
+// Whatever is out of the ordinary -- a literal piece that points past the stream, symbols that run out, a hole or a backward step in
+// the segment list, fewer than eight tokens -- is NOT handled here: the unit is left as it was (walk_ok stays 1) and the
 // two-kernel path behind this one decodes it, with the reference's error behaviour.  A unit done here is marked walk_ok = 4.
 #include "mic_dev.h"
 #include "mic_launch.h"
