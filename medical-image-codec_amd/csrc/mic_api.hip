@@ -390,15 +390,15 @@ const char *mic_hip_version(void) { return "mic-hip 0.2 (gfx950)"; }
 
 // device -> device copy on the calling thread's current device, complete on return (a session's result buffers are reused by its
 // next call: a caller that keeps them copies them out)
-int mic_hip_device_copy(void *d_dst, const void *d_src, size_t bytes) {
+int mic_hip_device_copy(void *d_dst, const void *d_src, size_t bytes) try {
     if ((!d_dst || !d_src) && bytes) return MIC_ERR_ARGS;
     if (bytes) HIP_TRY(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_set_device(int device) { return mic_hip_set_devices(&device, 1); }
+int mic_hip_set_device(int device) try { return mic_hip_set_devices(&device, 1); } catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_set_devices(const int *devices, int n) {
+int mic_hip_set_devices(const int *devices, int n) try {
     if (!devices || n <= 0 || n > 64) return MIC_ERR_ARGS;
     for (int i = 0; i < n; i++) {
         if (devices[i] < 0) return MIC_ERR_ARGS;
@@ -419,12 +419,12 @@ int mic_hip_set_devices(const int *devices, int n) {
     if (g_device != devices[0]) g_device_ok = false;
     g_device = devices[0];
     return ensure_device_locked();
-}
-int mic_hip_get_devices(int *devices, int cap) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_get_devices(int *devices, int cap) try {
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < (int)g_devices.size() && i < cap; i++) if (devices) devices[i] = g_devices[(size_t)i];
     return (int)g_devices.size();
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 const char *mic_hip_device_name(void) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -433,7 +433,7 @@ const char *mic_hip_device_name(void) {
 }
 
 int mic_hip_compress_frame(const uint16_t *pixels, int width, int height, uint16_t max_value, int nstates,
-                           uint8_t *out, size_t out_cap, size_t *out_len) {
+                           uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!pixels || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     mic_hip_enc_job j{};
     j.pixels = pixels; j.width = width; j.height = height; j.max_value = max_value; j.nstates = (uint16_t)nstates;
@@ -443,23 +443,23 @@ int mic_hip_compress_frame(const uint16_t *pixels, int width, int height, uint16
     if (rc) return rc;
     if (j.status == MIC_OK) *out_len = j.out_len;
     return j.status;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len, uint16_t *pixels_out, int width, int height) {
+int mic_hip_decompress_frame(const uint8_t *compressed, size_t compressed_len, uint16_t *pixels_out, int width, int height) try {
     if (!compressed || !pixels_out || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     mic_hip_dec_job j{};
     j.compressed = compressed; j.compressed_len = compressed_len; j.pixels_out = pixels_out; j.width = width; j.height = height;
     int rc = mic_hip_decompress_batch(&j, 1);
     if (rc) return rc;
     return j.status;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- bare FSE stage (fsecompressu16.go:19, fse2state.go:22/102, fse4state.go:24, fse8state.go:31, rans8state.go:31)
-int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uint8_t *out, size_t out_cap, size_t *out_len) {
+int mic_hip_fse_compress_u16(const uint16_t *symbols, size_t n, int flavour, uint8_t *out, size_t out_cap, size_t *out_len) try {
     return mic_hip_fse_compress_u16_ex(symbols, n, flavour, 0, out, out_cap, out_len);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, int table_log, uint8_t *out, size_t out_cap, size_t *out_len) {
+int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, int table_log, uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!symbols || !out || !out_len) return MIC_ERR_ARGS;
     if (!(flavour == 1 || flavour == 2 || flavour == 4 || flavour == 8 || flavour == 108)) return MIC_ERR_ARGS;
     if (table_log < 0 || table_log > MIC_MAX_TABLELOG) return MIC_ERR_ARGS;   // prepare(): "tableLog (%d) > maxTableLog (%d)", fseu16.go:136-138
@@ -491,17 +491,17 @@ int mic_hip_fse_compress_u16_ex(const uint16_t *symbols, size_t n, int flavour, 
     HIP_TRY(hipMemcpy(out, d_blobs, len, hipMemcpyDeviceToHost));
     *out_len = len;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *out, size_t out_cap, size_t *out_n) {
+int mic_hip_fse_decompress_u16_auto(const uint8_t *in, size_t in_len, uint16_t *out, size_t out_cap, size_t *out_n) try {
     return mic_hip_fse_decompress_u16_ex(in, in_len, 0, out, out_cap, out_n);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ScratchU16.DecompressLimit (fseu16.go:87-91): the reference compares len(OutU16) with the limit every time its 65536-symbol ring
 // wraps (fse2state.go:249/283, fse4state.go:246/..., fse8state.go, fsedecompressu16.go:318/353) and, for 1-state streams, once more
 // at the end (fsedecompressu16.go:372): an N-state stream of `count` symbols fails iff floor(count / 65536) * 65536 >= limit,
 // a 1-state stream iff its symbol count >= limit.  0 = the default, 2 GiB - 1.
-int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t decompress_limit, uint16_t *out, size_t out_cap, size_t *out_n) {
+int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t decompress_limit, uint16_t *out, size_t out_cap, size_t *out_n) try {
     if (decompress_limit < 0) return MIC_ERR_ARGS;
     const uint64_t limit = decompress_limit ? (uint64_t)decompress_limit : ((2ull << 30) - 1);
     if (in && in_len >= 6 && in[0] == 0xFF && (in[1] == 0x02 || in[1] == 0x04 || in[1] == 0x84 || in[1] == 0x08)) {
@@ -536,10 +536,10 @@ int mic_hip_fse_decompress_u16_ex(const uint8_t *in, size_t in_len, int64_t deco
     if (n) HIP_TRY(hipMemcpy(out, s->h_units[0].tok, n * 2, hipMemcpyDeviceToHost));
     *out_n = n;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- PICS / MIC2 headers (the container codecs themselves: mic_host_io.hip) ------------------------
-int mic_hip_pics_info(const uint8_t *c, size_t len, int *width, int *height, int *num_strips, int *strip_height) {
+int mic_hip_pics_info(const uint8_t *c, size_t len, int *width, int *height, int *num_strips, int *strip_height) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 20 || memcmp(c, "PICS", 4) != 0) return MIC_ERR_CORRUPT;   // parallelstrips.go:271-273
     int w = (int)get_u32(c + 4), h = (int)get_u32(c + 8), n = (int)get_u32(c + 12), sh = (int)get_u32(c + 16);
@@ -547,26 +547,26 @@ int mic_hip_pics_info(const uint8_t *c, size_t len, int *width, int *height, int
     if (w <= 0 || h <= 0 || n <= 0 || sh <= 0) return MIC_ERR_CORRUPT;   // :284-286
     if (width) *width = w; if (height) *height = h; if (num_strips) *num_strips = n; if (strip_height) *strip_height = sh;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 int mic_hip_mic2_compress_temporal(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
-                                   uint8_t *out, size_t out_cap, size_t *out_len) {
+                                   uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!frames || !out || !out_len || width <= 0 || height <= 0 || nframes <= 0) return MIC_ERR_ARGS;
     return mic2_temporal_compress(frames, width, height, nframes, max_value, out, out_cap, out_len);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_mic2_info(const uint8_t *c, size_t len, int *width, int *height, int *nframes, int *temporal) {
+int mic_hip_mic2_info(const uint8_t *c, size_t len, int *width, int *height, int *nframes, int *temporal) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 20 || memcmp(c, "MIC2", 4) != 0) return MIC_ERR_CORRUPT;   // multiframe.go:96-103
     int w = (int)get_u32(c + 4), h = (int)get_u32(c + 8), n = (int)get_u32(c + 12);
     if (n < 0 || (size_t)n > (len - 20) / 8) return MIC_ERR_CORRUPT;     // :112-116
     if (width) *width = w; if (height) *height = h; if (nframes) *nframes = n; if (temporal) *temporal = (c[16] & 0x02) != 0;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressFrame (multiframecompress.go:266-315): one frame of a MIC2 file.  Independent mode decodes just that
 // frame; temporal mode needs frames 0..idx (all their residual streams are decoded at once, mic_temporal.hip).
-int mic_hip_mic2_decompress_frame(const uint8_t *c, size_t len, int frame_idx, uint16_t *pixels_out, size_t pixels_cap) {
+int mic_hip_mic2_decompress_frame(const uint8_t *c, size_t len, int frame_idx, uint16_t *pixels_out, size_t pixels_cap) try {
     if (!c || !pixels_out) return MIC_ERR_ARGS;
     int w, h, n, temporal;
     int rc = mic_hip_mic2_info(c, len, &w, &h, &n, &temporal);
@@ -586,10 +586,10 @@ int mic_hip_mic2_decompress_frame(const uint8_t *c, size_t len, int frame_idx, u
     if (rc) return rc;
     memcpy(pixels_out, tmp.data() + npx * (size_t)frame_idx, npx * 2);
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- sessions ------------------------------------------------------------------------------------
-int mic_hip_session_create_on(int device, mic_hip_session **out, int max_units, size_t max_px_per_unit) {
+int mic_hip_session_create_on(int device, mic_hip_session **out, int max_units, size_t max_px_per_unit) try {
     if (!out || max_units <= 0 || max_px_per_unit == 0) return MIC_ERR_ARGS;
     int rc = check_device(device);
     if (rc) return rc;
@@ -600,13 +600,13 @@ int mic_hip_session_create_on(int device, mic_hip_session **out, int max_units, 
     if (rc) { s->release(); delete s; return rc; }
     *out = s;
     return MIC_OK;
-}
-int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_per_unit) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_create(mic_hip_session **out, int max_units, size_t max_px_per_unit) try {
     int dev;
     { std::lock_guard<std::mutex> lk(g_mu); dev = g_device; }
     return mic_hip_session_create_on(dev, out, max_units, max_px_per_unit);
-}
-int mic_hip_session_device(mic_hip_session *s) { return s ? s->device : -1; }
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_device(mic_hip_session *s) try { return s ? s->device : -1; } catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 // device memory the session holds right now (workspace slabs, staging, stores), and whether a batch has needed the tier-2 slabs
 size_t mic_hip_session_workspace_bytes(mic_hip_session *s, int *tier2) {
     if (!s) return 0;
@@ -616,41 +616,41 @@ size_t mic_hip_session_workspace_bytes(mic_hip_session *s, int *tier2) {
 void mic_hip_session_destroy(mic_hip_session *s) { if (s) { (void)s->activate(); s->release(); delete s; } }
 void *mic_hip_session_stream(mic_hip_session *s) { return s ? (void *)s->stream : nullptr; }
 
-int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) {
+int mic_hip_session_encode_enqueue(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n) try {
     if (!s || !d_pixels || !units) return MIC_ERR_ARGS;
     { const int arc = s->activate(); if (arc) return arc; }
     return session_encode_enqueue(s, d_pixels, units, n);
-}
-int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_encode_finish(mic_hip_session *s, const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) try {
     if (!s || !h_offsets || !h_status) return MIC_ERR_ARGS;
     { const int arc = s->activate(); if (arc) return arc; }
     return session_encode_finish(s, d_blobs, h_offsets, h_status, h_nstates);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 int mic_hip_session_encode(mic_hip_session *s, const uint16_t *d_pixels, const mic_hip_unit *units, int n,
-                           const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) {
+                           const uint8_t **d_blobs, uint64_t *h_offsets, int32_t *h_status, int32_t *h_nstates) try {
     int rc = mic_hip_session_encode_enqueue(s, d_pixels, units, n);
     if (rc) return rc;
     return mic_hip_session_encode_finish(s, d_blobs, h_offsets, h_status, h_nstates);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 int mic_hip_session_decode_enqueue(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets,
-                                   const mic_hip_unit *units, int n, uint16_t *d_pixels_out) {
+                                   const mic_hip_unit *units, int n, uint16_t *d_pixels_out) try {
     if (!s || !d_blobs || !h_offsets || !units || !d_pixels_out) return MIC_ERR_ARGS;
     { const int arc = s->activate(); if (arc) return arc; }
     return session_decode_enqueue(s, d_blobs, h_offsets, units, n, d_pixels_out);
-}
-int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_decode_finish(mic_hip_session *s, int32_t *h_status) try {
     if (!s || !h_status) return MIC_ERR_ARGS;
     { const int arc = s->activate(); if (arc) return arc; }
     return session_decode_finish(s, h_status);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 int mic_hip_session_decode(mic_hip_session *s, const uint8_t *d_blobs, const uint64_t *h_offsets, const mic_hip_unit *units, int n,
-                           uint16_t *d_pixels_out, int32_t *h_status) {
+                           uint16_t *d_pixels_out, int32_t *h_status) try {
     int rc = mic_hip_session_decode_enqueue(s, d_blobs, h_offsets, units, n, d_pixels_out);
     if (rc) return rc;
     return mic_hip_session_decode_finish(s, h_status);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 // debug probe (not part of the public header): raw result fields of unit i after a *_finish
-int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) {
+int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) try {
     if (!s || i < 0 || i >= s->n_last) return MIC_ERR_ARGS;
     const MicUnit &u = s->h_units[(size_t)i];
     out8[0] = u.ntok; out8[1] = u.blob_len; out8[2] = u.table_log; out8[3] = u.symbol_len;
@@ -658,27 +658,27 @@ int mic_hip_debug_unit(mic_hip_session *s, int i, uint32_t *out8) {
     out8[8] = u.count; out8[9] = u.bits_off; out8[10] = (uint32_t)u.nstates_used; out8[11] = (uint32_t)u.status; out8[12] = u.nseg; out8[13] = u.nsym; out8[14] = u.seg_cap;
     for (int k = 0; k < 16; k++) out8[16 + k] = u.dbg[k];
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 // debug probe (not in the public header): bytes of unit i's histogram slab after a *_finish (LS_DEBUG builds dump there)
-int mic_hip_debug_fetch_hist(mic_hip_session *s, int i, void *dst, size_t bytes) {
+int mic_hip_debug_fetch_hist(mic_hip_session *s, int i, void *dst, size_t bytes) try {
     if (!s || i < 0 || i >= s->n_last || bytes > kSym * 4) return MIC_ERR_ARGS;
     HIP_TRY(hipMemcpy(dst, s->h_units[(size_t)i].hist, bytes, hipMemcpyDeviceToHost));
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 // debug probe (not in the public header): the first n u16 of unit i's token slab after a *_finish
-int mic_hip_debug_fetch_tok(mic_hip_session *s, int i, void *dst, size_t n) {
+int mic_hip_debug_fetch_tok(mic_hip_session *s, int i, void *dst, size_t n) try {
     if (!s || i < 0 || i >= s->n_last || n > s->h_units[(size_t)i].tok_cap) return MIC_ERR_ARGS;
     HIP_TRY(hipMemcpy(dst, s->h_units[(size_t)i].tok, n * 2, hipMemcpyDeviceToHost));
     return MIC_OK;
-}
-int mic_hip_session_set_timing(mic_hip_session *s, int enabled) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_set_timing(mic_hip_session *s, int enabled) try {
     if (!s) return MIC_ERR_ARGS;
     s->timer.enabled = enabled != 0;
     s->timer.accumulate = enabled == 2;                                   // 2: sum over every launch chain until the next set_timing
     s->timer.clear();
     return MIC_OK;
-}
-int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *ms, int cap) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *ms, int cap) try {
     if (!s) return 0;
     s->t_names.clear(); s->t_ms.clear();
     if (s->timer.used >= 2) {
@@ -696,6 +696,6 @@ int mic_hip_session_last_timings(mic_hip_session *s, const char **names, float *
     int n = (int)std::min<size_t>(s->t_names.size(), (size_t)std::max(cap, 0));
     for (int i = 0; i < n; i++) { names[i] = s->t_names[(size_t)i].c_str(); ms[i] = s->t_ms[(size_t)i]; }
     return n;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 }  // extern "C"

@@ -383,7 +383,7 @@ extern "C" {
 
 // CompressWSI (wsicompress.go:27-171): 8-bit RGB (channels 3) or 8/16-bit greyscale (channels 1, little-endian samples)
 int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int channels, int bits_per_sample, int tile_w, int tile_h,
-                            int levels, uint8_t *out, size_t out_cap, size_t *out_len) {
+                            int levels, uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!rgb || !out || !out_len || width <= 0 || height <= 0 || tile_w < 0 || tile_h < 0) return MIC_ERR_ARGS;
     Mic3 fmt; fmt.channels = channels; fmt.bps = bits_per_sample; fmt.flags = 0x01 | (channels == 3 ? 0x02 : 0);   // defaults(), wsiformat.go:86-96
     if (!fmt.supported()) return MIC_ERR_UNSUPPORTED;
@@ -447,10 +447,10 @@ int mic_hip_wsi_compress_ex(const uint8_t *rgb, int width, int height, int chann
     }
     *out_len = hdr + total;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // CompressRGB (rgbcompress.go:25-27) = compressRGBTileBlob on the whole image: one "tile" of width x height
-int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) {
+int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!rgb || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
     Mic3 fmt; fmt.channels = 3; fmt.bps = 8; fmt.flags = 0x03;
@@ -470,10 +470,10 @@ int mic_hip_rgb_compress(const uint8_t *rgb, int width, int height, uint8_t *out
     memcpy(out, blob.data(), blob.size());
     *out_len = blob.size();
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressRGB (rgbcompress.go:31-33)
-int mic_hip_rgb_decompress(const uint8_t *c, size_t len, int width, int height, uint8_t *rgb_out, size_t out_cap) {
+int mic_hip_rgb_decompress(const uint8_t *c, size_t len, int width, int height, uint8_t *rgb_out, size_t out_cap) try {
     if (!c || !rgb_out || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     if ((size_t)width * height > ((size_t)1 << 26)) return MIC_ERR_UNSUPPORTED;
     if ((size_t)width * height * 3 > out_cap) return MIC_ERR_CAPACITY;
@@ -482,10 +482,10 @@ int mic_hip_rgb_decompress(const uint8_t *c, size_t len, int width, int height, 
     int rc = lease.acquire();
     if (rc) return rc;
     return decode_blobs(m, std::vector<TileBlob>(1, TileBlob{ c, len }), std::vector<int4>(1, make_int4(0, 0, width, height)), rgb_out, width, height);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // MICR file = "MICR", width, height (u32 LE), CompressRGB blob (writeMICRFile, cmd/mic-compress/main.go:62-91)
-int mic_hip_micr_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) {
+int mic_hip_micr_compress(const uint8_t *rgb, int width, int height, uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!out || !out_len) return MIC_ERR_ARGS;
     if (out_cap < 12) return MIC_ERR_CAPACITY;
     size_t n = 0;
@@ -494,26 +494,26 @@ int mic_hip_micr_compress(const uint8_t *rgb, int width, int height, uint8_t *ou
     memcpy(out, "MICR", 4); put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height);
     *out_len = 12 + n;
     return MIC_OK;
-}
-int mic_hip_micr_info(const uint8_t *c, size_t len, int *width, int *height) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_micr_info(const uint8_t *c, size_t len, int *width, int *height) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 12 || memcmp(c, "MICR", 4) != 0) return MIC_ERR_CORRUPT;
     const uint32_t w = get_u32(c + 4), h = get_u32(c + 8);
     if (w == 0 || h == 0 || w > (1u << 26) || h > (1u << 26)) return MIC_ERR_CORRUPT;
     if (width) *width = (int)w; if (height) *height = (int)h;
     return MIC_OK;
-}
-int mic_hip_micr_decompress(const uint8_t *c, size_t len, uint8_t *rgb_out, size_t out_cap) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_micr_decompress(const uint8_t *c, size_t len, uint8_t *rgb_out, size_t out_cap) try {
     int w = 0, h = 0;
     const int rc = mic_hip_micr_info(c, len, &w, &h);
     if (rc) return rc;
     return mic_hip_rgb_decompress(c + 12, len - 12, w, h, rgb_out, out_cap);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // MIC1 file = "MIC1", width, height, pipeline 1, payload length (u32 LE each), CompressSingleFrame stream
 // (writeMicFile, cmd/mic-compress/main.go:26-59; the stream's own magic tells the state count)
 int mic_hip_mic1_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int n_states,
-                          uint8_t *out, size_t out_cap, size_t *out_len) {
+                          uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!out || !out_len) return MIC_ERR_ARGS;
     if (out_cap < 20) return MIC_ERR_CAPACITY;
     size_t n = 0;
@@ -523,47 +523,47 @@ int mic_hip_mic1_compress(const uint16_t *pixels, int width, int height, uint16_
     memcpy(out, "MIC1", 4); put_u32(out + 4, (uint32_t)width); put_u32(out + 8, (uint32_t)height); put_u32(out + 12, 1); put_u32(out + 16, (uint32_t)n);
     *out_len = 20 + n;
     return MIC_OK;
-}
-int mic_hip_mic1_info(const uint8_t *c, size_t len, int *width, int *height) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_mic1_info(const uint8_t *c, size_t len, int *width, int *height) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 20 || memcmp(c, "MIC1", 4) != 0) return MIC_ERR_CORRUPT;
     const uint32_t w = get_u32(c + 4), h = get_u32(c + 8);
     if (w == 0 || h == 0 || w > (1u << 26) || h > (1u << 26) || get_u32(c + 12) != 1 || (size_t)get_u32(c + 16) > len - 20) return MIC_ERR_CORRUPT;
     if (width) *width = (int)w; if (height) *height = (int)h;
     return MIC_OK;
-}
-int mic_hip_mic1_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_mic1_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) try {
     int w = 0, h = 0;
     const int rc = mic_hip_mic1_info(c, len, &w, &h);
     if (rc) return rc;
     if ((size_t)w * h > out_cap_px) return MIC_ERR_CAPACITY;
     return mic_hip_decompress_frame(c + 20, get_u32(c + 16), pixels_out, w, h);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 int mic_hip_wsi_compress(const uint8_t *rgb, int width, int height, int tile_w, int tile_h, int levels,
-                         uint8_t *out, size_t out_cap, size_t *out_len) {
+                         uint8_t *out, size_t out_cap, size_t *out_len) try {
     return mic_hip_wsi_compress_ex(rgb, width, height, 3, 8, tile_w, tile_h, levels, out, out_cap, out_len);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // WSIHeader.Channels / BitsPerSample / ColorTransform (wsiformat.go:169-227)
-int mic_hip_wsi_format(const uint8_t *c, size_t len, int *channels, int *bits_per_sample, int *color_transform) {
+int mic_hip_wsi_format(const uint8_t *c, size_t len, int *channels, int *bits_per_sample, int *color_transform) try {
     if (!c) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
     if (channels) *channels = m.channels; if (bits_per_sample) *bits_per_sample = m.bps; if (color_transform) *color_transform = (m.flags & 0x02) ? 1 : 0;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ReadWSIHeader (wsicompress.go:299-306)
-int mic_hip_wsi_info(const uint8_t *c, size_t len, int *width, int *height, int *tile_w, int *tile_h, int *levels, uint64_t *total_tiles) {
+int mic_hip_wsi_info(const uint8_t *c, size_t len, int *width, int *height, int *tile_w, int *tile_h, int *levels, uint64_t *total_tiles) try {
     if (!c) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
     if (width) *width = m.w; if (height) *height = m.h; if (tile_w) *tile_w = m.tw; if (tile_h) *tile_h = m.th;
     if (levels) *levels = m.nlev; if (total_tiles) *total_tiles = m.total;
     return MIC_OK;
-}
-int mic_hip_wsi_level_info(const uint8_t *c, size_t len, int level, int *width, int *height, int *tiles_x, int *tiles_y) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_wsi_level_info(const uint8_t *c, size_t len, int level, int *width, int *height, int *tiles_x, int *tiles_y) try {
     if (!c) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
@@ -571,11 +571,11 @@ int mic_hip_wsi_level_info(const uint8_t *c, size_t len, int level, int *width, 
     const Level &L = m.lv[(size_t)level];
     if (width) *width = L.w; if (height) *height = L.h; if (tiles_x) *tiles_x = L.tx; if (tiles_y) *tiles_y = L.ty;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressWSITile (wsicompress.go:175-217): one tile, cropped at the level's edge
 int mic_hip_wsi_decompress_tile(const uint8_t *c, size_t len, int level, int tile_x, int tile_y,
-                                uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) {
+                                uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) try {
     if (!c || !rgb_out) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
@@ -592,10 +592,10 @@ int mic_hip_wsi_decompress_tile(const uint8_t *c, size_t len, int level, int til
     std::vector<size_t> tiles(1, (size_t)L.first + (size_t)tile_y * L.tx + tile_x);
     std::vector<int4> place(1, make_int4(0, 0, aw, ah));
     return decode_tiles(c, len, m, tiles, place, rgb_out, aw, ah);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // Whole pyramid level in one batch: every tile of the level, stitched (viewer / bench path)
-int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_t *rgb_out, size_t out_cap) {
+int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_t *rgb_out, size_t out_cap) try {
     if (!c || !rgb_out) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
@@ -614,12 +614,12 @@ int mic_hip_wsi_decompress_level(const uint8_t *c, size_t len, int level, uint8_
     DefaultLease lease;
     if ((rc = lease.acquire())) return rc;
     return decode_tiles(c, len, m, tiles, place, rgb_out, L.w, L.h);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressWSIRegion (wsicompress.go:219-297): the tiles that overlap the rectangle are decoded in one batch into
 // their tile-aligned bounding box, the rectangle is cut out of it.  w / h are clamped to the level like the reference does.
 int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x, int y, int w, int h,
-                                  uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) {
+                                  uint8_t *rgb_out, size_t out_cap, int *out_w, int *out_h) try {
     if (!c || !rgb_out) return MIC_ERR_ARGS;
     Mic3 m; int rc = parse_mic3(c, len, m);
     if (rc) return rc;
@@ -654,7 +654,7 @@ int mic_hip_wsi_decompress_region(const uint8_t *c, size_t len, int level, int x
     if (out_w) *out_w = w;
     if (out_h) *out_h = h;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 
 }  // extern "C"
@@ -756,7 +756,7 @@ int store_level_tiles(mic_hip_session *s, mic_hip_wsi_store &W, const void *d_im
 extern "C" {
 
 int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int width, int height, int channels, int bits_per_sample,
-                               int tile_w, int tile_h, int levels, uint64_t *total_tiles, uint64_t *compressed_bytes) {
+                               int tile_w, int tile_h, int levels, uint64_t *total_tiles, uint64_t *compressed_bytes) try {
     if (!s || !d_pixels || width <= 0 || height <= 0 || tile_w < 0 || tile_h < 0) return MIC_ERR_ARGS;
     Mic3 fmt; fmt.channels = channels; fmt.bps = bits_per_sample; fmt.flags = 0x01 | (channels == 3 ? 0x02 : 0);
     if (!fmt.supported()) return MIC_ERR_UNSUPPORTED;
@@ -808,7 +808,7 @@ int mic_hip_session_wsi_encode(mic_hip_session *s, const uint8_t *d_pixels, int 
         *compressed_bytes = n;
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // WriteMIC3 (wsiformat.go:99-165) around the store: header, level table, tile table, tile blobs ([Ylen][Colen][Cglen] + planes,
 // wsicompress.go:341-363; grey: the bare plane).  One device-to-host copy of the store's bytes.
@@ -878,7 +878,7 @@ static int wsi_assemble(mic_hip_session *s, std::vector<uint64_t> &tlen, uint64_
 
 // The store as the container's payload, on the device: *d_payload (valid until the session's next wsi call), its size, and the
 // byte length of every tile in container order (tile_lens[cap >= total tiles], host).  What a multi-GPU writer gathers.
-int mic_hip_session_wsi_payload(mic_hip_session *s, const uint8_t **d_payload, uint64_t *payload_bytes, uint64_t *tile_lens, size_t cap) {
+int mic_hip_session_wsi_payload(mic_hip_session *s, const uint8_t **d_payload, uint64_t *payload_bytes, uint64_t *tile_lens, size_t cap) try {
     if (!s || !d_payload || !payload_bytes || !tile_lens || !s->wsi) return MIC_ERR_ARGS;
     int rc = s->activate();
     if (rc) return rc;
@@ -889,9 +889,9 @@ int mic_hip_session_wsi_payload(mic_hip_session *s, const uint8_t **d_payload, u
     for (size_t t = 0; t < tlen.size(); t++) tile_lens[t] = tlen[t];
     *d_payload = (const uint8_t *)s->wsi_payload.p; *payload_bytes = total;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len) {
+int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!s || !out || !out_len || !s->wsi) return MIC_ERR_ARGS;
     int rc = s->activate();
     if (rc) return rc;
@@ -922,10 +922,10 @@ int mic_hip_session_wsi_write(mic_hip_session *s, uint8_t *out, size_t out_cap, 
     }
     *out_len = hdr + (size_t)total;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // every tile of one level, from the store, into a device image of the level's size (bytes per pixel as the slide's)
-int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_pixels_out, size_t out_cap) {
+int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_pixels_out, size_t out_cap) try {
     if (!s || !d_pixels_out || !s->wsi) return MIC_ERR_ARGS;
     int rc = s->activate();
     if (rc) return rc;
@@ -982,13 +982,13 @@ int mic_hip_session_wsi_decode_level(mic_hip_session *s, int level, uint8_t *d_p
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_session_wsi_levels(mic_hip_session *s, int *levels, int *widths, int *heights, int cap) {
+int mic_hip_session_wsi_levels(mic_hip_session *s, int *levels, int *widths, int *heights, int cap) try {
     if (!s || !s->wsi || !levels) return MIC_ERR_ARGS;
     *levels = (int)s->wsi->lv.size();
     for (int i = 0; i < *levels && i < cap; i++) { if (widths) widths[i] = s->wsi->lv[(size_t)i].w; if (heights) heights[i] = s->wsi->lv[(size_t)i].h; }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 }  // extern "C"

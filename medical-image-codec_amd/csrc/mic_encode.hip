@@ -1073,7 +1073,6 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
     uint32_t q = first_q;
     uint64_t acc = 0; uint32_t filled = (uint32_t)(gstart & 63);
     uint64_t lead_val = 0; bool have_lead = false;
-    uint64_t pend = 0; bool have_pend = false;                            // the even unit of a pair, waiting for its odd partner
     typedef unsigned long long te_u2 __attribute__((ext_vector_type(2)));
     uint64_t abl_chk = 0;
 #ifndef TE_RING
@@ -1097,7 +1096,6 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
         if (TE_ABL & 2) { q++; return; }
         if (TE_ABL & 4) { abl_chk ^= v; q++; return; }                          // (timing only: the pass without its stores)
         if (q == first_q && !own_first) { lead_val = v; have_lead = true; }
-#ifndef TE_NO_RING4
         // Units leave in aligned groups of FOUR (32 bytes, two 16-byte stores back to back): the memory side writes 32-byte sectors,
         // and a lone 16-byte store 1.4 KiB from its lane neighbours' left a sector half written when its line was evicted -- the
         // counters showed the stream written 2.75 times.
@@ -1108,12 +1106,6 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
             for (int i = 0; i < TE_RING - 1; i++) rg[i] = k == (uint32_t)i ? v : rg[i];
             rmask |= 1u << k;
         }
-#else
-        else if (q & 1u) {
-            if (have_pend) { te_u2 pr; pr.x = pend; pr.y = v; *(mic_gp<te_u2>)(words64 + (q - 1)) = pr; have_pend = false; }
-            else words64[q] = v;
-        } else { pend = v; have_pend = true; }
-#endif
         q++;
     };
 #ifdef TE_CHECK
@@ -1168,11 +1160,7 @@ __device__ TE_FN_ATTR void te_encode(MicUnit &u, uint16_t *s_stab, const uint2 *
     }
     if (mybits > 0 && filled > 0) emit(acc);                             // the thread's last, partial unit
     if ((TE_ABL & 4) && abl_chk == 0x1234567ull) words64[first_q] = abl_chk;
-#ifndef TE_NO_RING4
     if (rmask) flush4((q - 1u) & ~(TE_RING - 1u), 0ull, false);           // (a group the next thread completes)
-#else
-    if (have_pend) words64[q - 1] = pend;                                 // (an even unit whose partner belongs to the next thread)
-#endif
 #ifdef TE_NO_HANDOFF    // diagnostic: the barrier round 3 had here before MIC_GROUP_HANDOFF
     __threadfence_block(); __syncthreads();
 #else

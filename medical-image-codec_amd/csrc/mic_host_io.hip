@@ -451,8 +451,13 @@ int run_shards(std::vector<Grp> &G, std::vector<Unt> &U, Run run_one) {
         S[(size_t)k].rc = rc;
     };
     std::vector<std::thread> th;
-    for (int k = 1; k < shards; k++) th.emplace_back(work, k);
+    int started = 1;                                  // shards 1 .. started - 1 have a thread; what could not get one runs here, one after the other
+    try {
+        th.reserve((size_t)shards);
+        for (; started < shards; started++) th.emplace_back(work, started);
+    } catch (...) { }                                 // (no exception crosses the C ABI: a thread the system refuses costs overlap, not the call)
     work(0);
+    for (int k = started; k < shards; k++) work(k);
     for (auto &t : th) t.join();
     int rc = MIC_OK;
     for (int k = 0; k < shards; k++) {
@@ -495,11 +500,11 @@ extern "C" {
 
 // The cut of `n` weighted items into `shards` contiguous shards that the batch entry points use across the devices of
 // mic_hip_set_devices (first[0 .. shards]: item i belongs to shard k iff first[k] <= i < first[k + 1]); no device needed.
-int mic_hip_shard_plan(const uint64_t *weights, int n, int shards, int *first) {
+int mic_hip_shard_plan(const uint64_t *weights, int n, int shards, int *first) try {
     if (!weights || !first || n < 0 || shards <= 0) return MIC_ERR_ARGS;
     shard_plan(weights, n, shards, first);
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // Pinned host memory for a caller's frame and stream buffers: the entry points below DMA such buffers in place instead of
 // staging them through the transfer engine's slots.
@@ -511,7 +516,7 @@ void *mic_hip_host_alloc(size_t bytes) {
 }
 void mic_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
+int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) try {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
     int rc = ensure_device();
@@ -533,9 +538,9 @@ int mic_hip_compress_batch(mic_hip_enc_job *jobs, int njobs) {
         j.out_len = G[k].status == MIC_OK ? G[k].written : 0;
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
+int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) try {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
     int rc = ensure_device();
@@ -554,10 +559,10 @@ int mic_hip_decompress_batch(mic_hip_dec_job *jobs, int njobs) {
     if ((rc = decode_sharded(G, U))) return rc;
     for (size_t k = 0; k < G.size(); k++) jobs[job_of[k]].status = G[k].status;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- PICS (parallelstrips.go) ----------------------------------------------------------------
-int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) {
+int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) try {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
     int rc = ensure_device();
@@ -602,14 +607,14 @@ int mic_hip_pics_compress_batch(mic_hip_pics_enc_job *jobs, int njobs) {
         j.out_len = g.hdr + g.written;
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 int mic_hip_pics_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
-                          uint8_t *out, size_t out_cap, size_t *out_len) {
+                          uint8_t *out, size_t out_cap, size_t *out_len) try {
     return mic_hip_pics_compress_ex(pixels, width, height, max_value, num_strips, nstates, out, out_cap, out_len, nullptr);
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 int mic_hip_pics_compress_ex(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips, int nstates,
-                             uint8_t *out, size_t out_cap, size_t *out_len, int *failed_strip) {
+                             uint8_t *out, size_t out_cap, size_t *out_len, int *failed_strip) try {
     if (failed_strip) *failed_strip = -1;
     if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
     if (!(nstates == 2 || nstates == 4 || nstates == 8)) return MIC_ERR_ARGS;
@@ -621,9 +626,9 @@ int mic_hip_pics_compress_ex(const uint16_t *pixels, int width, int height, uint
     if (j.status == MIC_OK) *out_len = j.out_len;
     else if (failed_strip) *failed_strip = j.failed_strip;
     return j.status;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs) {
+int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs) try {
     if (!jobs || njobs < 0) return MIC_ERR_ARGS;
     if (njobs == 0) return MIC_OK;
     int rc = ensure_device();
@@ -661,12 +666,12 @@ int mic_hip_pics_decompress_batch(mic_hip_pics_dec_job *jobs, int njobs) {
     if ((rc = decode_sharded(G, U))) return rc;
     for (size_t k = 0; k < G.size(); k++) { jobs[job_of[k]].status = G[k].status; jobs[job_of[k]].failed_strip = G[k].failed; }   // "strip %d: %w", parallelstrips.go:316
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_pics_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) {
+int mic_hip_pics_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) try {
     return mic_hip_pics_decompress_ex(c, len, pixels_out, width, height, nullptr);
-}
-int mic_hip_pics_decompress_ex(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height, int *failed_strip) {
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
+int mic_hip_pics_decompress_ex(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height, int *failed_strip) try {
     if (failed_strip) *failed_strip = -1;
     if (!c || !pixels_out) return MIC_ERR_ARGS;
     mic_hip_pics_dec_job j{};
@@ -674,11 +679,11 @@ int mic_hip_pics_decompress_ex(const uint8_t *c, size_t len, uint16_t *pixels_ou
     const int rc = mic_hip_pics_decompress_batch(&j, 1);
     if (rc == MIC_OK && j.status != MIC_OK && failed_strip) *failed_strip = j.failed_strip;
     return rc ? rc : j.status;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- MIC2 independent mode (multiframe.go, multiframecompress.go:179-261) -----------------------
 int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nframes, uint16_t max_value,
-                          uint8_t *out, size_t out_cap, size_t *out_len) {
+                          uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!frames || !out || !out_len || width <= 0 || height <= 0 || nframes <= 0) return MIC_ERR_ARGS;
     const size_t npx = (size_t)width * (size_t)height;
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
@@ -720,9 +725,9 @@ int mic_hip_mic2_compress(const uint16_t *frames, int width, int height, int nfr
     }
     *out_len = header + G[0].written;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, size_t frames_cap_px) {
+int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, size_t frames_cap_px) try {
     if (!c || !frames_out) return MIC_ERR_ARGS;
     int w, h, n, temporal;
     int rc = mic_hip_mic2_info(c, len, &w, &h, &n, &temporal);
@@ -749,6 +754,6 @@ int mic_hip_mic2_decompress(const uint8_t *c, size_t len, uint16_t *frames_out, 
     if ((rc = decode_sharded(G, U))) return rc;
     for (const DecGroup &g : G) if (g.status != MIC_OK) return g.status;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 }  // extern "C"

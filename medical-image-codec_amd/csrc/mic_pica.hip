@@ -58,7 +58,7 @@ extern "C" {
 
 // CompressSingleFrameGrad (multiframecompress.go:111-129): gradient-adaptive predictor, two-state FSE, one-state fallback
 int mic_hip_compress_frame_grad(const uint16_t *pixels, int width, int height, uint16_t max_value,
-                                uint8_t *out, size_t out_cap, size_t *out_len) {
+                                uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!pixels || !out || !out_len || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     const size_t npx = (size_t)width * (size_t)height;
     if (npx > ((size_t)1 << 28)) return MIC_ERR_UNSUPPORTED;
@@ -79,10 +79,10 @@ int mic_hip_compress_frame_grad(const uint16_t *pixels, int width, int height, u
     HIP_TRY(hipMemcpy(out, d_blobs + offs[0], len, hipMemcpyDeviceToHost));
     *out_len = len;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressSingleFrameGrad (multiframecompress.go:132-142)
-int mic_hip_decompress_frame_grad(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) {
+int mic_hip_decompress_frame_grad(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) try {
     if (!c || !pixels_out || width <= 0 || height <= 0) return MIC_ERR_ARGS;
     if (len == 0) return MIC_ERR_CORRUPT;
     const size_t npx = (size_t)width * (size_t)height;
@@ -103,11 +103,11 @@ int mic_hip_decompress_frame_grad(const uint8_t *c, size_t len, uint16_t *pixels
     if (st != MIC_OK) return st;
     HIP_TRY(hipMemcpy(pixels_out, s->io_px.p, npx * 2, hipMemcpyDeviceToHost));
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // CompressParallelStripsAdaptive (parallelstripsadaptive.go:54-137)
 int mic_hip_pica_compress(const uint16_t *pixels, int width, int height, uint16_t max_value, int num_strips,
-                          uint8_t *out, size_t out_cap, size_t *out_len) {
+                          uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!pixels || !out || !out_len || width <= 0 || height <= 0 || num_strips <= 0) return MIC_ERR_ARGS;
     if ((size_t)width * (size_t)height > ((size_t)1 << 31)) return MIC_ERR_UNSUPPORTED;
     if (num_strips > height) num_strips = height;                                          // :61-66
@@ -196,9 +196,9 @@ int mic_hip_pica_compress(const uint16_t *pixels, int width, int height, uint16_
     }
     *out_len = header + total;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_pica_info(const uint8_t *c, size_t len, int *width, int *height, int *num_strips) {
+int mic_hip_pica_info(const uint8_t *c, size_t len, int *width, int *height, int *num_strips) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 16 || memcmp(c, "PICA", 4) != 0) return MIC_ERR_CORRUPT;                      // :142-144
     const int w = (int)get_u32(c + 4), h = (int)get_u32(c + 8), n = (int)get_u32(c + 12);
@@ -206,10 +206,10 @@ int mic_hip_pica_info(const uint8_t *c, size_t len, int *width, int *height, int
     if (w <= 0 || h <= 0 || n <= 0) return MIC_ERR_CORRUPT;                                 // :154-156
     if (width) *width = w; if (height) *height = h; if (num_strips) *num_strips = n;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // DecompressParallelStripsAdaptive (parallelstripsadaptive.go:141-214)
-int mic_hip_pica_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) {
+int mic_hip_pica_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, int width, int height) try {
     if (!c || !pixels_out) return MIC_ERR_ARGS;
     int w, h, n;
     int rc = mic_hip_pica_info(c, len, &w, &h, &n);
@@ -262,6 +262,6 @@ int mic_hip_pica_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, 
     }
     HIP_TRY(hipMemcpy(pixels_out, s->io_px.p, npx * 2, hipMemcpyDeviceToHost));
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 }  // extern "C"

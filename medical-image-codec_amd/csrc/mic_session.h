@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <atomic>
 #include <vector>

@@ -904,7 +904,7 @@ extern "C" {
 // frames: nframes x rows*cols u16, contiguous.  Frame i's file goes to out + i * out_stride, its length to out_lens[i], its
 // status to status[i] (a frame that fails does not stop the others).
 int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int rows, int cols, uint16_t max_value, int levels,
-                                      uint8_t *out, size_t out_stride, size_t *out_lens, int32_t *status) {
+                                      uint8_t *out, size_t out_stride, size_t *out_lens, int32_t *status) try {
     if (!frames || !out || !out_lens || !status || nframes <= 0 || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
     const size_t n = (size_t)rows * (size_t)cols;
     if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
@@ -936,11 +936,11 @@ int mic_hip_wavelet_v2_compress_batch(const uint16_t *frames, int nframes, int r
         }
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // WaveletV2RLEFSECompressU16 / WaveletV2SIMDRLEFSECompressU16 (waveletfsecompressu16.go:303, :374)
 int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint16_t max_value, int levels,
-                                uint8_t *out, size_t out_cap, size_t *out_len) {
+                                uint8_t *out, size_t out_cap, size_t *out_len) try {
     if (!pixels || !out || !out_len || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
     if (out_cap < 11) return MIC_ERR_CAPACITY;
     size_t len = 0; int32_t st = 0;
@@ -949,9 +949,9 @@ int mic_hip_wavelet_v2_compress(const uint16_t *pixels, int rows, int cols, uint
     if (st != MIC_OK) return st;
     *out_len = len;
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
-int mic_hip_wavelet_v2_info(const uint8_t *c, size_t len, int *rows, int *cols, int *max_value, int *levels) {
+int mic_hip_wavelet_v2_info(const uint8_t *c, size_t len, int *rows, int *cols, int *max_value, int *levels) try {
     if (!c) return MIC_ERR_ARGS;
     if (len < 11) return MIC_ERR_CORRUPT;                                                   // :494-496
     if (rows) *rows = (int)((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
@@ -959,12 +959,12 @@ int mic_hip_wavelet_v2_info(const uint8_t *c, size_t len, int *rows, int *cols, 
     if (max_value) *max_value = c[8] | (c[9] << 8);
     if (levels) *levels = c[10];
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // WaveletV2RLEFSEDecompressU16 over nframes files of ONE shape (same rows, cols, levels) in one launch chain; pixels_out receives
 // nframes x rows*cols u16, status[i] frame i's status.  Files of another shape than the first: MIC_ERR_ARGS for that frame.
 int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_t *lens, int nframes, uint16_t *pixels_out, size_t out_cap_px,
-                                        int32_t *status) {
+                                        int32_t *status) try {
     if (!files || !lens || !pixels_out || !status || nframes <= 0) return MIC_ERR_ARGS;
     int rows, cols, maxv, levels;
     int rc = mic_hip_wavelet_v2_info(files[0], lens[0], &rows, &cols, &maxv, &levels);
@@ -1007,22 +1007,22 @@ int mic_hip_wavelet_v2_decompress_batch(const uint8_t *const *files, const size_
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // WaveletV2RLEFSEDecompressU16 / WaveletV2SIMDRLEFSEDecompressU16 (:380-425, :493-534)
-int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) {
+int mic_hip_wavelet_v2_decompress(const uint8_t *c, size_t len, uint16_t *pixels_out, size_t out_cap_px) try {
     if (!c || !pixels_out) return MIC_ERR_ARGS;
     int32_t st = 0;
     const int rc = mic_hip_wavelet_v2_decompress_batch(&c, &len, 1, pixels_out, out_cap_px, &st);
     return rc ? rc : st;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 // ---- device-resident forms (what bench.py times for BASELINE config 3): frames, streams and pixels stay in HBM ----------------
 // nframes frames of rows x cols u16, contiguous at d_frames -> their WaveletV2 streams WITHOUT the 11-byte file header (rows, cols,
 // maxValue, levels: the caller has them), packed back to back on the device: *d_streams, h_offsets[nframes + 1], h_status[nframes];
 // *levels_applied = the level count the header would carry (waveletfsecompressu16.go:321-330).
 int mic_hip_session_wavelet_v2_encode(mic_hip_session *s, const uint16_t *d_frames, int nframes, int rows, int cols, int levels,
-                                      const uint8_t **d_streams, uint64_t *h_offsets, int32_t *h_status, int *levels_applied) {
+                                      const uint8_t **d_streams, uint64_t *h_offsets, int32_t *h_status, int *levels_applied) try {
     if (!s || !d_frames || !d_streams || !h_offsets || !h_status || nframes <= 0 || rows <= 0 || cols <= 0) return MIC_ERR_ARGS;
     const size_t n = (size_t)rows * (size_t)cols;
     if (n > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
@@ -1037,10 +1037,10 @@ int mic_hip_session_wavelet_v2_encode(mic_hip_session *s, const uint16_t *d_fram
     if ((rc = wv_compress_frames(s, d_frames, nframes, rows, cols, applied, nullptr, st, d_streams, h_offsets))) return rc;
     for (int i = 0; i < nframes; i++) h_status[i] = st[(size_t)i];
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 // The inverse: nframes header-less streams at d_streams + h_offsets[i] (all of one shape / level count) -> pixels at d_pixels_out.
 int mic_hip_session_wavelet_v2_decode(mic_hip_session *s, const uint8_t *d_streams, const uint64_t *h_offsets, int nframes,
-                                      int rows, int cols, int levels, uint16_t *d_pixels_out, int32_t *h_status) {
+                                      int rows, int cols, int levels, uint16_t *d_pixels_out, int32_t *h_status) try {
     if (!s || !d_streams || !h_offsets || !d_pixels_out || !h_status || nframes <= 0 || rows <= 0 || cols <= 0 || levels < 0 || levels > 8) return MIC_ERR_ARGS;
     if ((size_t)rows * (size_t)cols > ((size_t)1 << 27)) return MIC_ERR_UNSUPPORTED;
     int rc = s->activate();
@@ -1049,6 +1049,6 @@ int mic_hip_session_wavelet_v2_decode(mic_hip_session *s, const uint8_t *d_strea
     if ((rc = wv_decompress_frames(s, d_streams, d_pixels_out, nframes, h_offsets, rows, cols, levels, st))) return rc;
     for (int i = 0; i < nframes; i++) h_status[i] = st[(size_t)i];
     return MIC_OK;
-}
+} catch (const std::bad_alloc &) { return MIC_ERR_NOMEM; } catch (...) { return MIC_ERR_INTERNAL; }   // (no C++ exception crosses the C ABI)
 
 }  // extern "C"
