@@ -58,6 +58,45 @@ int main(void) {
     for (int i = 0; i < NJ; i++) if (dj[i].status != MIC_OK) { fprintf(stderr, "dec job %d status %d\n", i, dj[i].status); return 1; }
     if (memcmp(img, back, npx * 2) != 0) { fprintf(stderr, "batch mismatch\n"); return 1; }
     printf("batch of %d frames: round trip ok\n", NJ);
+
+    /* round 4: two shards on one device (what a host with several GPUs does with their indices), the plan of the cut, and the
+     * strip index a failing PICS call names (parallelstrips.go:97) */
+    {
+        const int two[2] = { 0, 0 };
+        int got[4] = { -1, -1, -1, -1 };
+        if (mic_hip_set_devices(two, 2) != MIC_OK || mic_hip_get_devices(got, 4) != 2 || got[0] != 0 || got[1] != 0) { fprintf(stderr, "set_devices\n"); return 1; }
+        const uint64_t wts[5] = { 10, 10, 10, 10, 40 };
+        int first[3] = { -1, -1, -1 };
+        if (mic_hip_shard_plan(wts, 5, 2, first) != MIC_OK || first[0] != 0 || first[2] != 5 || first[1] < 1 || first[1] > 4) { fprintf(stderr, "shard_plan %d %d %d\n", first[0], first[1], first[2]); return 1; }
+        memset(back, 0, npx * 2);
+        rc = mic_hip_compress_batch(ej, NJ);
+        for (int i = 0; rc == MIC_OK && i < NJ; i++) { if (ej[i].status != MIC_OK) rc = ej[i].status; dj[i].compressed_len = ej[i].out_len; }
+        if (rc == MIC_OK) rc = mic_hip_decompress_batch(dj, NJ);
+        if (rc != MIC_OK || memcmp(img, back, npx * 2) != 0) { fprintf(stderr, "sharded batch rc=%d / mismatch\n", rc); return 1; }
+        const int one[1] = { 0 };
+        if (mic_hip_set_devices(one, 1) != MIC_OK) return 1;
+        /* strip 5 of 32 (15 rows, 9600 pixels) is uniform noise over the whole 12-bit range: too few pixels for their alphabet, no FSE
+         * flavour makes it smaller -- the call fails and says where */
+        enum { NS = 32 };
+        const size_t cap32 = MIC_HIP_PICS_BOUND(W, H, NS);
+        uint8_t *comp32 = malloc(cap32);
+        uint16_t *bad = malloc(npx * 2);
+        memcpy(bad, img, npx * 2);
+        for (size_t i = (size_t)(5 * (H / NS)) * W; i < (size_t)(6 * (H / NS)) * W; i++) bad[i] = (uint16_t)(rnd(&seed) & MAXV);
+        int strip = -7; size_t blen = 0;
+        rc = mic_hip_pics_compress_ex(bad, W, H, MAXV, NS, 2, comp32, cap32, &blen, &strip);
+        if (rc == MIC_OK || strip != 5) { fprintf(stderr, "pics_compress_ex rc=%d strip=%d (expected a failure in strip 5)\n", rc, strip); return 1; }
+        strip = -7;
+        rc = mic_hip_pics_compress_ex(img, W, H, MAXV, 4, 2, comp, cap, &blen, &strip);
+        if (rc != MIC_OK || strip != -1) { fprintf(stderr, "pics_compress_ex on a good image rc=%d strip=%d\n", rc, strip); return 1; }
+        comp[blen - 1] = 0;                                               /* the last strip loses its end mark (bitreader.go:36-38) */
+        strip = -7;
+        rc = mic_hip_pics_decompress_ex(comp, blen, back, W, H, &strip);
+        if (rc == MIC_OK || strip != 3) { fprintf(stderr, "pics_decompress_ex rc=%d strip=%d (expected a failure in strip 3)\n", rc, strip); return 1; }
+        free(comp32);
+        free(bad);
+        printf("two shards, shard plan, failing strips named: ok\n");
+    }
     free(img); free(back); free(comp);
     for (int i = 0; i < NJ; i++) free(outs[i]);
     return 0;
