@@ -1,8 +1,10 @@
-import sys, os, importlib, json
-sys.path.insert(0, "/root/repo")
-os.chdir(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-sys.path.insert(0, os.getcwd())
-import bench, __graft_entry__ as entry, torch
+"""Rehearsal of bench.py's one-process multi-device end_to_end leg on a one-GPU box: the same device listed twice (two shards, two
+sessions, one PCIe link), sixteen frames.  usage: python tools/rehearse_e2e.py"""
+import importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, __graft_entry__ as entry
+import torch
 mic = entry.load_package()
 synth = importlib.import_module("medical_image_codec_amd.synth")
 dev = torch.device("cuda:0")
