@@ -555,21 +555,13 @@ __global__ void __launch_bounds__(TR_THREADS) k_dec_translate(MicUnit *units) {
     __syncthreads();
     typedef uint32_t tr_v4 __attribute__((ext_vector_type(4)));
     const uint32_t smask = size - 1;                                        // a state carries its +size offset: index = state - size
-    // (a translating thread fetches its states of the NEXT tile before it works on this one: with a barrier per tile a group had one
-    // tile -- 3 KiB -- in flight, seven groups 21 KiB a CU, short of what the memory's latency times its bandwidth asks for)
-    tr_v4 vnext = tr_v4{0u, 0u, 0u, 0u};
-    if (wave != 0) { const uint32_t i0 = (tid - 64) * 8; if (i0 + 8 <= min((uint32_t)TR_TILE, ntok)) vnext = __builtin_nontemporal_load((const tr_v4 *)(tok + i0)); }
     for (uint32_t base = 0, it = 0; base < ntok; base += TR_TILE, it++) {
         const uint32_t tile_end = min(base + TR_TILE, ntok);
         uint16_t *tile = s_tile[it & 1];
         if (wave != 0) {
             const uint32_t l = (tid - 64) * 8, i0 = base + l;
-            const tr_v4 v = vnext;
-            {
-                const uint32_t n0 = i0 + TR_TILE, nend = min(base + 2u * TR_TILE, ntok);
-                if (base + TR_TILE < ntok && n0 + 8 <= nend) vnext = __builtin_nontemporal_load((const tr_v4 *)(tok + n0));
-            }
             if (i0 + 8 <= tile_end) {
+                const tr_v4 v = __builtin_nontemporal_load((const tr_v4 *)(tok + i0));
                 tr_v4 o;
                 o.x = (uint32_t)s_sym[v.x & smask] | ((uint32_t)s_sym[(v.x >> 16) & smask] << 16);
                 o.y = (uint32_t)s_sym[v.y & smask] | ((uint32_t)s_sym[(v.y >> 16) & smask] << 16);
